@@ -1,0 +1,102 @@
+"""ctypes front end of oracle/librt_oracle.so (the plain-C CPU restatement).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by raytracer_amd."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = os.path.join(ROOT, "oracle", "librt_oracle.so")
+
+
+class RoScene(ctypes.Structure):
+    _fields_ = [("materials", ctypes.c_void_p), ("n_materials", ctypes.c_int),
+                ("hittables", ctypes.c_void_p), ("n_hittables", ctypes.c_int),
+                ("lights", ctypes.c_void_p), ("n_lights", ctypes.c_int)]
+
+
+class RoCounters(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_ulonglong) for k in ("primary", "closest", "shadow", "tests", "draws")]
+
+
+class RoRng(ctypes.Structure):
+    _fields_ = [("r", ctypes.c_uint * 31), ("f", ctypes.c_int), ("b", ctypes.c_int)]
+
+
+_hit_dtype = np.dtype([("type", np.int32), ("a", np.float32, 3), ("b", np.float32, 3), ("radius", np.float32), ("material", np.int32)])
+_light_dtype = np.dtype([("type", np.int32), ("v", np.float32, 3)])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "port"], check=True, capture_output=True)
+        _lib = ctypes.CDLL(_LIB)
+        _lib.ro_render.restype = ctypes.c_int
+        _lib.ro_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.ro_camera_init.argtypes = [ctypes.c_void_p] + [ctypes.c_float] * 5
+        _lib.ro_probe_max_depth.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_void_p]
+        _lib.ro_srand.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        _lib.ro_rand.argtypes = [ctypes.c_void_p]
+        _lib.ro_quantise.argtypes = [ctypes.c_float]
+        _lib.ro_quantise.restype = ctypes.c_ubyte
+    return _lib
+
+
+def _pack(scene):
+    mats, htype, ha, hb, hr, hm, ltype, lv = scene.arrays()
+    mats = np.ascontiguousarray(mats)
+    hit = np.zeros(len(htype), dtype=_hit_dtype)
+    hit["type"], hit["a"], hit["b"], hit["radius"], hit["material"] = htype, ha, hb, hr, hm
+    lig = np.zeros(len(ltype), dtype=_light_dtype)
+    lig["type"], lig["v"] = ltype, lv
+    rs = RoScene(mats.ctypes.data, len(mats), hit.ctypes.data, len(hit), lig.ctypes.data, len(lig))
+    return rs, (mats, hit, lig)
+
+
+def camera(scene, W, H):
+    cam = np.zeros(35, dtype=np.float32)
+    lib().ro_camera_init(cam.ctypes.data, scene.fov, float(W), float(H), scene.znear, scene.zfar)
+    return cam
+
+
+def render(scene, W, H, samples, maxdepth, seed_base=0, row0=0, rows=None, threads=1, want_emission=True):
+    """-> (rgb uint8 [rows,W,3], emission float32 [rows,W,4] or None, counters dict)"""
+    rows = H - row0 if rows is None else rows
+    rs, keep = _pack(scene)
+    cam = camera(scene, W, H)
+    rgb = np.zeros((rows, W, 3), dtype=np.uint8)
+    em = np.zeros((rows, W, 4), dtype=np.float32) if want_emission else None
+    cnt = RoCounters()
+    rc = lib().ro_render(ctypes.byref(rs), cam.ctypes.data, W, H, samples, maxdepth, seed_base, row0, rows, threads,
+                         rgb.ctypes.data, em.ctypes.data if em is not None else None, ctypes.byref(cnt))
+    if rc != 0:
+        raise ValueError("ro_render rejected the arguments")
+    del keep
+    return rgb, em, {"primary": cnt.primary, "closest": cnt.closest, "shadow": cnt.shadow, "tests": cnt.tests, "rand_draws": cnt.draws}
+
+
+def probe_max_depth(scene, W, H, maxdepth, seed_base=0):
+    rs, keep = _pack(scene)
+    cam = camera(scene, W, H)
+    flags = np.zeros((H, W), dtype=np.uint8)
+    rc = lib().ro_probe_max_depth(ctypes.byref(rs), cam.ctypes.data, W, H, maxdepth, seed_base, flags.ctypes.data)
+    assert rc == 0
+    del keep
+    return flags
+
+
+def rand_sequence(seed, n):
+    g = RoRng()
+    lib().ro_srand(ctypes.byref(g), seed & 0xFFFFFFFF)
+    return [lib().ro_rand(ctypes.byref(g)) for _ in range(n)]
+
+
+def quantise(c):
+    return int(lib().ro_quantise(float(c)))

@@ -1,0 +1,100 @@
+"""Pins the CPU restatement (oracle/rt_oracle.c) against fixtures produced by the REAL reference
+(oracle/_ref/ref_oracle = unmodified reference headers; tests/golden/make_golden.py) and against glibc."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from raytracer_amd import scenes
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("probe_"))
+
+
+def load_case(path):
+    z = np.load(path)
+    sc = scenes.Scene.from_text(bytes(z["scene"]).decode())
+    W, H, samples, depth, seed = (int(v) for v in z["params"])
+    return z, sc, W, H, samples, depth, seed
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_oracle_matches_reference_golden(path):
+    z, sc, W, H, samples, depth, seed = load_case(path)
+    rgb, em, cnt = oracle_lib.render(sc, W, H, samples, depth, seed)
+    assert np.array_equal(rgb, z["rgb"]), "8-bit image differs from the reference's"
+    assert np.array_equal(em.view(np.uint32), z["emission"].view(np.uint32)), "emission buffer is not bit-identical"
+    assert [cnt[k] for k in ("primary", "closest", "shadow", "tests", "rand_draws")] == [int(v) for v in z["counters"]]
+    assert np.array_equal(oracle_lib.camera(sc, W, H).view(np.uint32), z["camera"].view(np.uint32))
+
+
+def test_oracle_is_thread_count_and_band_independent():
+    z, sc, W, H, samples, depth, seed = load_case(os.path.join(GOLDEN, "glass_mirror_96x80_s2_d3_seed9.npz"))
+    rgb4, em4, cnt4 = oracle_lib.render(sc, W, H, samples, depth, seed, threads=4)
+    assert np.array_equal(rgb4, z["rgb"]) and np.array_equal(em4.view(np.uint32), z["emission"].view(np.uint32))
+    assert cnt4["closest"] == int(z["counters"][1])
+    top, _, _ = oracle_lib.render(sc, W, H, samples, depth, seed, row0=0, rows=33)
+    bot, _, _ = oracle_lib.render(sc, W, H, samples, depth, seed, row0=33, rows=H - 33)
+    assert np.array_equal(np.concatenate([top, bot]), z["rgb"])
+
+
+def test_camera_matrices_match_glm_bits():
+    with open(os.path.join(GOLDEN, "camera_bits.json")) as fh:
+        cams = json.load(fh)
+    for key, bits in cams.items():
+        W, H = (int(v) for v in key.split("x"))
+        cam = oracle_lib.camera(scenes.default4(), W, H)
+        assert [int(b) for b in cam.view(np.uint32)] == bits, key
+    # SURVEY.md Appendix C known answers for Camera(60, 1024, 512, 0.01, 1000)
+    cam = oracle_lib.camera(scenes.default4(), 1024, 512)
+    assert float(cam[3]).hex() == "0x1.279a740000000p+0"           # invProj[0][0]
+    assert float(cam[3 + 5]).hex() == "0x1.279a740000000p-1"       # invProj[1][1]
+    assert float(cam[3 + 16]).hex() == "0x1.ea68320000000p-1"      # invView[0][0]
+
+
+def test_rng_matches_glibc_known_answers():
+    with open(os.path.join(GOLDEN, "glibc_rand.json")) as fh:
+        known = json.load(fh)
+    for seed, seq in known.items():
+        assert oracle_lib.rand_sequence(int(seed), len(seq)) == seq, seed
+    assert known["1"][0] == 1804289383 and known["0"] == known["1"]      # srand(0) == srand(1)
+
+
+def test_rng_matches_live_libc_on_random_seeds():
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand.argtypes = [ctypes.c_uint]
+    rs = np.random.RandomState(0)
+    for seed in [int(s) for s in rs.randint(0, 2**32, size=40, dtype=np.uint64)]:
+        libc.srand(seed)
+        want = [libc.rand() for _ in range(400)]
+        assert oracle_lib.rand_sequence(seed, 400) == want, seed
+
+
+def test_quantise_is_double_sqrt_truncation():
+    # structs.h:12-17: (unsigned char)(sqrt((double)c) * 255.0)
+    rs = np.random.RandomState(1)
+    for c in list(rs.uniform(0, 1, 2000).astype(np.float32)) + [0.0, 1.0, 0.25, np.float32(1.0) - np.float32(2**-24)]:
+        assert oracle_lib.quantise(c) == int(np.sqrt(np.float64(np.float32(c))) * 255.0)
+    assert oracle_lib.quantise(float("nan")) == 0
+
+
+def test_probe_mode_matches_reference():
+    z = np.load(os.path.join(GOLDEN, "probe_glass_mirror_128x64_d3_seed0.npz"))
+    sc = scenes.Scene.from_text(bytes(z["scene"]).decode())
+    W, H, _, depth, seed = (int(v) for v in z["params"])
+    assert np.array_equal(oracle_lib.probe_max_depth(sc, W, H, depth, seed), z["flags"])
+
+
+def test_scene_text_round_trip():
+    for name, builder in scenes.BUILTIN.items():
+        sc = builder()
+        again = scenes.Scene.from_text(sc.to_text())
+        assert again.materials == sc.materials and again.hittables == sc.hittables and again.lights == sc.lights, name
+    with pytest.raises(ValueError):
+        scenes.Scene.from_text("sphere 1 2 3\n")
+    with pytest.raises(ValueError):
+        scenes.Scene.from_text("torus 1 2 3\n")
