@@ -1,0 +1,152 @@
+/* rt_amd.h -- C-ABI of the MI355X (gfx950) rendering backend for DevDuoItaly/Raytracer's TraceRay hot path.
+ *
+ * The reference has no plugin/FFI interface; its boundary is a source-level convention: whoever owns the pixel
+ * loop calls AntiAliasing() per sample and fills pixel[] / emissionPixel[] (reference src/main.cpp:295-320,
+ * src/tests/speedUp.cpp:91-113, the function-shaped instance being
+ *   double Render(Camera&, Hittable* world, Light* lights, Material* materials, int threads)
+ * at src/tests/speedUp.cpp:26,69).  This header is what a binding for that loop nest links against.  Each entry
+ * point names the reference code it replaces.  Plain C, plain pointers and sizes; no exceptions cross it.
+ *
+ * Conventions: every function returns RT_OK (0) or a negative rt_status; the caller owns every buffer it passes
+ * (the library copies what it keeps); a context is bound to one GPU and is not thread-safe; calls are synchronous.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RT_OK               =  0,
+    RT_ERR_INVALID_ARG  = -1,  /* null pointer, non-positive size, rows outside the frame ...               */
+    RT_ERR_NO_DEVICE    = -2,  /* no such GPU / not a gfx950 device                                          */
+    RT_ERR_HIP          = -3,  /* a HIP runtime call failed; rt_last_hip_error() has the code                */
+    RT_ERR_SCENE        = -4,  /* material index out of range, unknown hittable / light type                 */
+    RT_ERR_UNSUPPORTED  = -5,  /* material.reflection > 1 (unbounded recursion in the reference too),
+                                  max_depth above RT_MAX_DEPTH, scene larger than the LDS staging budget     */
+    RT_ERR_NO_SCENE     = -6,  /* rt_render_rows before rt_upload_scene                                      */
+    RT_ERR_DEVICE_FAULT = -7   /* the kernel reported an internal bound violation (bounce stack overflow)    */
+} rt_status;
+
+enum { RT_SPHERE = 0, RT_PLANE = 1, RT_CUBE = 2 };        /* reference src/hittables/{sphere,plane,cube}.h   */
+enum { RT_DIRLIGHT = 0, RT_POINTLIGHT = 1 };              /* src/lights/directionalLight.h; point: repo-defined */
+
+#define RT_MAX_DEPTH     64      /* largest accepted rt_params.max_depth (MAXDEPTH, src/main.cpp:27)          */
+#define RT_MAX_HITTABLES 4096    /* LDS staging budget: 32 B per hittable                                     */
+#define RT_MAX_LIGHTS    64
+#define RT_MAX_MATERIALS 256     /* Sphere/Plane take a uint8_t material index (sphere.h:10, plane.h:10)      */
+
+typedef struct rt_ctx rt_ctx;
+
+/* Flattened scene, host memory, structure of arrays.  Replaces the device-side `new Sphere/new HittablesList/
+ * new DirectionalLight/new LightsList` of src/main.cu:69-90 and the Material upload of src/main.cu:517-530.
+ * Hittables stay in list order (closest-hit ties go to the earlier one, src/hittables/hittablesList.h:27).
+ *   materials : n_materials x 10 floats, exactly the layout of `struct Material` (src/material.h:5-11):
+ *               color.rgb, roughness, reflection, refraction, emissionColor.rgb, glowStrength
+ *   h_type    : RT_SPHERE / RT_PLANE / RT_CUBE
+ *   h_a       : n x 3  sphere centre | plane centre | cube min corner
+ *   h_b       : n x 3  (unused)      | plane normal (normalised by the library like plane.h:11) | cube size
+ *   h_radius  : n      sphere radius
+ *   h_material: n      index into materials (spheres and planes are truncated to uint8_t like the reference ctors)
+ *   l_type    : RT_DIRLIGHT / RT_POINTLIGHT
+ *   l_v       : n x 3  direction as passed to DirectionalLight's ctor (the library stores normalize(-v),
+ *               directionalLight.h:9) | point-light position */
+typedef struct {
+    int32_t        n_materials;
+    const float*   materials;
+    int32_t        n_hittables;
+    const int32_t* h_type;
+    const float*   h_a;
+    const float*   h_b;
+    const float*   h_radius;
+    const int32_t* h_material;
+    int32_t        n_lights;
+    const int32_t* l_type;
+    const float*   l_v;
+} rt_scene_soa;
+
+/* What the kernels consume of `class Camera` (src/camera.h:11-47): m_Position and the two inverse matrices,
+ * column-major like glm::mat4. */
+typedef struct {
+    float position[3];
+    float inv_proj[16];
+    float inv_view[16];
+} rt_camera35f;
+
+/* The reference's compile-time knobs (src/main.cpp:20-27) as run-time parameters, plus the row selection.
+ * Rows rendered by one call: local row r (0 <= r < rows) is frame row
+ *     y = row0 + (r / band_rows) * band_stride + (r % band_rows)        when band_rows > 0
+ *     y = row0 + r                                                      when band_rows == 0
+ * so a rank of an N-GPU job renders every N-th band (cyclic bands, DESIGN.md "multi-GPU").  Outputs are packed:
+ * local row r starts at rgb_out + r*width*3 and emission_out + r*width*4. */
+typedef struct {
+    int32_t width, height;       /* WIDTH, HEIGHT                                                            */
+    int32_t samples;             /* SAMPLES; each sample traces 4 primary rays (src/renderer.h:167-195)       */
+    int32_t max_depth;           /* MAXDEPTH, passed to AntiAliasing as maxTotalDepth                        */
+    int64_t seed_base;           /* stands in for time(NULL) in rand.h:7: pixel seed = seed_base + x + y*W   */
+    int32_t row0, rows;
+    int32_t band_rows, band_stride;
+    int32_t flags;               /* RT_FLAG_* */
+} rt_params;
+
+#define RT_FLAG_COUNT_LIKE_REFERENCE 1  /* count every shadow query the reference would issue (slower kernel) */
+
+/* Query tallies with the reference's meaning: primary = W*rows*samples*4; closest = TraceRay closest-hit queries
+ * (src/renderer.h:40); shadow = hasIntersect / point-light occlusion queries (directionalLight.h:13); tests =
+ * primitive intersect() calls; rand_draws = RANDOM_UNIT calls.  Filled only with RT_FLAG_COUNT_LIKE_REFERENCE. */
+typedef struct {
+    uint64_t primary, closest, shadow, tests, rand_draws;
+} rt_counters;
+
+/* Creates a context on GPU `device_ordinal` (HIP ordinal).  Replaces the cudaMalloc/cudaDeviceSetLimit set-up of
+ * src/main.cu:469-483. */
+int rt_create(rt_ctx** out, int device_ordinal);
+void rt_destroy(rt_ctx* ctx);
+
+/* Validates and uploads a scene (see rt_scene_soa). */
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* scene);
+
+/* Camera(fov, width, height, near, far) of src/camera.h:11-22 (eye (-3,6,10) -> (0,3,0), GLM perspectiveFov /
+ * lookAt / inverse in GLM's operation order), host arithmetic only. */
+int rt_camera_init(rt_camera35f* cam, float fov_deg, float width, float height, float z_near, float z_far);
+
+/* The hot path: replaces the tile lambda of src/main.cpp:289-330 (== the `kernel` of src/main.cu:38-67) for the
+ * selected rows.  rgb_out: rows*width*3 bytes of `pixel` (src/structs.h:8-25), emission_out: rows*width*4 floats
+ * of `emissionPixel` (src/structs.h:28-44) or NULL, counters: NULL unless RT_FLAG_COUNT_LIKE_REFERENCE.
+ * rgb_out / emission_out may be host or device pointers (device pointers must belong to the context's GPU). */
+int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* params,
+                   uint8_t* rgb_out, float* emission_out, rt_counters* counters);
+
+/* Depth probe of src/tests/singlePixel.cpp:65-90 (MaxRayDistance, src/renderer.h:204-219): one centre ray per
+ * pixel; flags_out[x + y*width] = (maxDepth >= max_depth).  flags_out: host or device, width*height bytes. */
+int rt_probe_max_depth(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* params, uint8_t* flags_out);
+
+/* Reassembles a frame from per-rank packed cyclic bands after the gather (the role of the Redis RPOP recompose
+ * loop, src/main.cpp:375-395).  gathered: nranks blocks of rows_per_rank*width*bytes_per_pixel (rank-major, each
+ * block packed as rt_render_rows writes it for row0 = rank*band_rows, band_stride = nranks*band_rows); frame_out:
+ * height*width*bytes_per_pixel.  Both device pointers on the context's GPU. */
+int rt_deinterleave_bands(rt_ctx* ctx, const void* gathered, void* frame_out, int32_t width, int32_t height,
+                          int32_t bytes_per_pixel, int32_t band_rows, int32_t nranks, int32_t rows_per_rank);
+
+/* Duration in milliseconds of the last rt_render_rows kernel, from HIP events on the context's stream. */
+float rt_last_kernel_ms(const rt_ctx* ctx);
+/* hipError_t of the last failing HIP call (0 if none). */
+int rt_last_hip_error(const rt_ctx* ctx);
+const char* rt_strerror(int status);
+
+/* Unit-test hooks: run single device functions of the hot path over arrays (host pointers).
+ *   rt_debug_rand     : out[i*n_draws + k] = k-th rand() after srand(seeds[i])              (src/rand.h:7,9)
+ *   rt_debug_quantise : out[i] = pixel::Set channel value for in[i]                          (src/structs.h:12-17)
+ *   rt_debug_intersect: one ray against hittable `index` of the uploaded scene; out = {hit, distance,
+ *                       position.xyz, normal.xyz} per ray (rays: n x 6 floats origin, direction) */
+int rt_debug_rand(rt_ctx* ctx, const uint32_t* seeds, int32_t n_seeds, int32_t n_draws, int32_t* out);
+int rt_debug_quantise(rt_ctx* ctx, const float* in, int32_t n, uint8_t* out);
+int rt_debug_intersect(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays, float* out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,421 @@
+// C-ABI layer (include/rt_amd.h): context, scene validation + flattening into the kernels' record layout,
+// launches, staging of host outputs.  No oracle, no CPU rendering fallback: without a gfx950 device every entry
+// point that needs one fails with RT_ERR_NO_DEVICE / RT_ERR_HIP.
+#include "rt_amd.h"
+#include "rt_launch.h"
+#include "../host/camera.h"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+struct rt_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.0f;
+    int last_hip = 0;
+
+    // uploaded scene
+    bool has_scene = false;
+    int n_hit = 0, n_lights = 0, n_mat = 0;
+    bool mixed = false, nonsphere = false;
+    void* d_scene = nullptr;       // hrec | lights | mats
+    size_t scene_bytes = 0;
+    const float4* d_hrec = nullptr; const float4* d_lights = nullptr; const float* d_mats = nullptr;
+
+    // small device words: 4 counters (u64) + fault flag
+    unsigned long long* d_counters = nullptr;
+    int* d_fault = nullptr;
+
+    // staging for host-pointer outputs (grown on demand)
+    void* d_stage_rgb = nullptr; size_t stage_rgb_bytes = 0;
+    void* d_stage_em = nullptr;  size_t stage_em_bytes = 0;
+};
+
+#define HIP_TRY(ctx, expr)                                   \
+    do {                                                     \
+        hipError_t e__ = (expr);                             \
+        if (e__ != hipSuccess) { (ctx)->last_hip = (int)e__; return RT_ERR_HIP; } \
+    } while (0)
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1; bool ok = false;
+    explicit DeviceGuard(int dev) { ok = hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+bool is_device_pointer(const void* p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int grow(rt_ctx* ctx, void** buf, size_t* have, size_t need)
+{
+    if (*have >= need) return RT_OK;
+    if (*buf) { HIP_TRY(ctx, hipFree(*buf)); *buf = nullptr; *have = 0; }
+    HIP_TRY(ctx, hipMalloc(buf, need));
+    *have = need;
+    return RT_OK;
+}
+
+// number of refraction parents a path can stack: multiplier *= 0.9f until it is < 0.001f (renderer.h:30,118)
+int refraction_chain_bound()
+{
+    int n = 0;
+    for (float m = 1.0f; !(m < 0.001f); m = m * 0.9f) ++n;
+    return n;
+}
+
+int check_params(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p)
+{
+    if (!ctx || !cam || !p) return RT_ERR_INVALID_ARG;
+    if (p->width <= 0 || p->height <= 0 || p->samples <= 0 || p->max_depth < 0) return RT_ERR_INVALID_ARG;
+    if ((int64_t)p->width * p->height > (int64_t)1 << 30) return RT_ERR_INVALID_ARG;
+    if (p->max_depth > RT_MAX_DEPTH) return RT_ERR_UNSUPPORTED;
+    if (p->row0 < 0 || p->rows < 0 || p->band_rows < 0 || p->band_stride < 0) return RT_ERR_INVALID_ARG;
+    if (p->rows > 0) {
+        int last;
+        if (p->band_rows > 0) {
+            if (p->band_stride < p->band_rows) return RT_ERR_INVALID_ARG;
+            const int r = p->rows - 1;
+            last = p->row0 + (r / p->band_rows) * p->band_stride + (r % p->band_rows);
+        } else {
+            last = p->row0 + p->rows - 1;
+        }
+        if (last >= p->height) return RT_ERR_INVALID_ARG;
+    }
+    if (!ctx->has_scene) return RT_ERR_NO_SCENE;
+    return RT_OK;
+}
+
+void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, KernelArgs& a)
+{
+    std::memcpy(a.cam, cam, sizeof(float) * 35);
+    a.width = p->width; a.height = p->height; a.samples = p->samples; a.max_depth = p->max_depth;
+    a.seed_base = (unsigned int)(uint64_t)p->seed_base;
+    a.row0 = p->row0; a.rows = p->rows; a.band_rows = p->band_rows; a.band_stride = p->band_stride;
+    a.tiles_x = (p->width + 15) / 16; a.tiles_y = (p->rows + 15) / 16;
+    a.n_hit = ctx->n_hit; a.n_lights = ctx->n_lights; a.n_mat = ctx->n_mat;
+    a.hrec = ctx->d_hrec; a.lights = ctx->d_lights; a.mats = ctx->d_mats;
+    a.rgb = nullptr; a.emission = nullptr; a.counters = ctx->d_counters; a.fault = ctx->d_fault;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_strerror(int status)
+{
+    switch (status) {
+    case RT_OK:               return "ok";
+    case RT_ERR_INVALID_ARG:  return "invalid argument";
+    case RT_ERR_NO_DEVICE:    return "no usable gfx950 device";
+    case RT_ERR_HIP:          return "HIP runtime error (see rt_last_hip_error)";
+    case RT_ERR_SCENE:        return "malformed scene (material index / hittable type / light type)";
+    case RT_ERR_UNSUPPORTED:  return "unsupported (reflection > 1, max_depth > RT_MAX_DEPTH or scene too large)";
+    case RT_ERR_NO_SCENE:     return "no scene uploaded";
+    case RT_ERR_DEVICE_FAULT: return "device reported a bounce-stack overflow";
+    default:                  return "unknown status";
+    }
+}
+
+int rt_create(rt_ctx** out, int device_ordinal)
+{
+    if (!out) return RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return RT_ERR_NO_DEVICE; }
+    if (device_ordinal < 0 || device_ordinal >= ndev) return RT_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return RT_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RT_ERR_NO_DEVICE;   // the code object is gfx950 only
+
+    rt_ctx* ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    ctx->device = device_ordinal;
+    DeviceGuard g(device_ordinal);
+    if (!g.ok) { delete ctx; return RT_ERR_NO_DEVICE; }
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 4 * sizeof(unsigned long long) + sizeof(int) * 2);
+    if (e != hipSuccess) { rt_destroy(ctx); return RT_ERR_HIP; }
+    ctx->d_fault = (int*)(ctx->d_counters + 4);
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* ctx)
+{
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_scene) (void)hipFree(ctx->d_scene);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_stage_rgb) (void)hipFree(ctx->d_stage_rgb);
+    if (ctx->d_stage_em) (void)hipFree(ctx->d_stage_em);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rt_last_hip_error(const rt_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+float rt_last_kernel_ms(const rt_ctx* ctx) { return ctx ? ctx->last_ms : 0.0f; }
+
+int rt_camera_init(rt_camera35f* cam, float fov_deg, float width, float height, float z_near, float z_far)
+{
+    if (!cam || !(width > 0.0f) || !(height > 0.0f) || !(fov_deg > 0.0f)) return RT_ERR_INVALID_ARG;
+    Camera c(fov_deg, width, height, z_near, z_far);
+    cam->position[0] = c.GetPosition().x; cam->position[1] = c.GetPosition().y; cam->position[2] = c.GetPosition().z;
+    std::memcpy(cam->inv_proj, c.GetInverseProjectionMatrix().m, sizeof(float) * 16);
+    std::memcpy(cam->inv_view, c.GetInverseViewMatrix().m, sizeof(float) * 16);
+    return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
+{
+    if (!ctx || !s) return RT_ERR_INVALID_ARG;
+    if (s->n_materials < 0 || s->n_hittables < 0 || s->n_lights < 0) return RT_ERR_INVALID_ARG;
+    if ((s->n_materials > 0 && !s->materials) || (s->n_lights > 0 && (!s->l_type || !s->l_v)) ||
+        (s->n_hittables > 0 && (!s->h_type || !s->h_a || !s->h_b || !s->h_radius || !s->h_material)))
+        return RT_ERR_INVALID_ARG;
+    if (s->n_hittables > RT_MAX_HITTABLES || s->n_lights > RT_MAX_LIGHTS || s->n_materials > RT_MAX_MATERIALS)
+        return RT_ERR_UNSUPPORTED;
+
+    bool mixed = false;
+    for (int i = 0; i < s->n_materials; ++i) {
+        const float reflection = s->materials[10 * i + 4], refraction = s->materials[10 * i + 5];
+        // reflection > 1 lets the multiplier grow: the reference's recursion is then bounded by nothing but depth
+        // for reflections and by nothing at all through refractions (renderer.h:82,118)
+        if (reflection > 1.0f || reflection != reflection || refraction != refraction) return RT_ERR_UNSUPPORTED;
+        if (reflection > 0.0f && refraction > 0.0f) mixed = true;
+    }
+
+    const int nh = s->n_hittables, nl = s->n_lights, nm = s->n_materials;
+    std::vector<float> img((size_t)nh * 8 + (size_t)nl * 4 + (size_t)nm * 10 + 4, 0.0f);
+    float* hrec = img.data();
+    float* lights = hrec + (size_t)nh * 8;
+    float* mats = lights + (size_t)nl * 4;
+    bool nonsphere = false;
+    for (int i = 0; i < nh; ++i) {
+        const int type = s->h_type[i];
+        int material = s->h_material[i];
+        const float* a = s->h_a + 3 * i; const float* b = s->h_b + 3 * i;
+        float* r = hrec + 8 * i;
+        r[0] = a[0]; r[1] = a[1]; r[2] = a[2];
+        if (type == RT_SPHERE) {
+            material = (uint8_t)material;                                   // sphere.h:10 takes uint8_t
+            r[3] = s->h_radius[i] * s->h_radius[i];                         // sphere.h:19
+        } else if (type == RT_PLANE) {
+            material = (uint8_t)material;                                   // plane.h:10
+            const rtm::vec3 n = rtm::normalize(rtm::vec3(b[0], b[1], b[2])); // plane.h:11
+            r[4] = n.x; r[5] = n.y; r[6] = n.z;
+            nonsphere = true;
+        } else if (type == RT_CUBE) {
+            r[4] = a[0] + b[0]; r[5] = a[1] + b[1]; r[6] = a[2] + b[2];     // cube.h:17,33,37
+            nonsphere = true;
+        } else {
+            return RT_ERR_SCENE;
+        }
+        if (material < 0 || material >= nm) return RT_ERR_SCENE;
+        const int bits = type | (material << 2);
+        std::memcpy(&r[7], &bits, 4);
+    }
+    for (int i = 0; i < nl; ++i) {
+        const int type = s->l_type[i];
+        const float* v = s->l_v + 3 * i;
+        float* r = lights + 4 * i;
+        if (type == RT_DIRLIGHT) {
+            const rtm::vec3 d = rtm::normalize(-rtm::vec3(v[0], v[1], v[2]));  // directionalLight.h:9
+            r[0] = d.x; r[1] = d.y; r[2] = d.z;
+        } else if (type == RT_POINTLIGHT) {
+            r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
+        } else {
+            return RT_ERR_SCENE;
+        }
+        std::memcpy(&r[3], &type, 4);
+    }
+    if (nm > 0) std::memcpy(mats, s->materials, sizeof(float) * 10 * (size_t)nm);
+
+    if (rt_launch_lds_bytes(nh, nl, nm) > 160 * 1024) return RT_ERR_UNSUPPORTED;
+
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    const size_t bytes = img.size() * sizeof(float);
+    if (bytes > ctx->scene_bytes) {
+        if (ctx->d_scene) { HIP_TRY(ctx, hipFree(ctx->d_scene)); ctx->d_scene = nullptr; ctx->scene_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_scene, bytes));
+        ctx->scene_bytes = bytes;
+    }
+    ctx->has_scene = false;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scene, img.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->d_hrec = (const float4*)ctx->d_scene;
+    ctx->d_lights = (const float4*)((const float*)ctx->d_scene + (size_t)nh * 8);
+    ctx->d_mats = (const float*)ctx->d_scene + (size_t)nh * 8 + (size_t)nl * 4;
+    ctx->n_hit = nh; ctx->n_lights = nl; ctx->n_mat = nm;
+    ctx->mixed = mixed; ctx->nonsphere = nonsphere;
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
+                   uint8_t* rgb_out, float* emission_out, rt_counters* counters)
+{
+    int rc = check_params(ctx, cam, p);
+    if (rc != RT_OK) return rc;
+    const bool count = (p->flags & RT_FLAG_COUNT_LIKE_REFERENCE) != 0;
+    if (count && !counters) return RT_ERR_INVALID_ARG;
+    if (!rgb_out && !emission_out && !count) return RT_ERR_INVALID_ARG;
+    if (counters) std::memset(counters, 0, sizeof(*counters));
+    if (p->rows == 0) { ctx->last_ms = 0.0f; return RT_OK; }
+
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+
+    KernelArgs a;
+    fill_args(ctx, cam, p, a);
+    const size_t npix = (size_t)p->width * p->rows;
+    const bool rgb_dev = rgb_out && is_device_pointer(rgb_out);
+    const bool em_dev = emission_out && is_device_pointer(emission_out);
+    if (rgb_out) {
+        if (rgb_dev) a.rgb = rgb_out;
+        else { rc = grow(ctx, &ctx->d_stage_rgb, &ctx->stage_rgb_bytes, npix * 3); if (rc) return rc; a.rgb = (unsigned char*)ctx->d_stage_rgb; }
+    }
+    if (emission_out) {
+        if (em_dev) a.emission = (float4*)emission_out;
+        else { rc = grow(ctx, &ctx->d_stage_em, &ctx->stage_em_bytes, npix * 16); if (rc) return rc; a.emission = (float4*)ctx->d_stage_em; }
+    }
+
+    LaunchTraits t;
+    t.emission = emission_out != nullptr;
+    t.mixed = ctx->mixed;
+    t.nonsphere = ctx->nonsphere;
+    t.count = count;
+    // frames on the bounce stack <= reflection parents (max_depth) + refraction parents (66)
+    t.deep = refraction_chain_bound() + p->max_depth > RT_STACK_SHALLOW || p->max_depth > RT_PEND_SHALLOW - 1;
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long) + sizeof(int) * 2, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(ctx, rt_launch_render(a, t, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+
+    if (rgb_out && !rgb_dev) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, a.rgb, npix * 3, hipMemcpyDeviceToHost, ctx->stream));
+    if (emission_out && !em_dev) HIP_TRY(ctx, hipMemcpyAsync(emission_out, a.emission, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long words[5] = { 0, 0, 0, 0, 0 };
+    HIP_TRY(ctx, hipMemcpyAsync(words, ctx->d_counters, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
+
+    int fault; std::memcpy(&fault, &words[4], sizeof(int));
+    if (fault) return RT_ERR_DEVICE_FAULT;
+    if (count) {
+        counters->primary = (uint64_t)npix * (uint64_t)p->samples * 4u;
+        counters->closest = words[0]; counters->shadow = words[1]; counters->tests = words[2]; counters->rand_draws = words[3];
+    }
+    return RT_OK;
+}
+
+int rt_probe_max_depth(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, uint8_t* flags_out)
+{
+    int rc = check_params(ctx, cam, p);
+    if (rc != RT_OK) return rc;
+    if (!flags_out) return RT_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+
+    KernelArgs a;
+    fill_args(ctx, cam, p, a);
+    a.row0 = 0; a.rows = p->height; a.band_rows = 0; a.band_stride = 0;
+    a.tiles_y = (p->height + 15) / 16;
+    const size_t npix = (size_t)p->width * p->height;
+    const bool dev = is_device_pointer(flags_out);
+    if (dev) a.rgb = flags_out;
+    else { rc = grow(ctx, &ctx->d_stage_rgb, &ctx->stage_rgb_bytes, npix); if (rc) return rc; a.rgb = (unsigned char*)ctx->d_stage_rgb; }
+    LaunchTraits t = { false, true, true, true, false };
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long) + sizeof(int) * 2, ctx->stream));
+    HIP_TRY(ctx, rt_launch_probe(a, t, ctx->stream));
+    if (!dev) HIP_TRY(ctx, hipMemcpyAsync(flags_out, a.rgb, npix, hipMemcpyDeviceToHost, ctx->stream));
+    int fault = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&fault, ctx->d_fault, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return fault ? RT_ERR_DEVICE_FAULT : RT_OK;
+}
+
+int rt_deinterleave_bands(rt_ctx* ctx, const void* gathered, void* frame_out, int32_t width, int32_t height,
+                          int32_t bytes_per_pixel, int32_t band_rows, int32_t nranks, int32_t rows_per_rank)
+{
+    if (!ctx || !gathered || !frame_out) return RT_ERR_INVALID_ARG;
+    if (width <= 0 || height <= 0 || bytes_per_pixel <= 0 || band_rows <= 0 || nranks <= 0 || rows_per_rank <= 0) return RT_ERR_INVALID_ARG;
+    // the last frame row must exist in its rank's block
+    const int last = height - 1, band = last / band_rows;
+    if ((band / nranks) * band_rows + (last % band_rows) >= rows_per_rank) return RT_ERR_INVALID_ARG;
+    if (!is_device_pointer(gathered) || !is_device_pointer(frame_out)) return RT_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    HIP_TRY(ctx, rt_launch_deinterleave(gathered, frame_out, width * bytes_per_pixel, height, band_rows, nranks, rows_per_rank, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_debug_rand(rt_ctx* ctx, const uint32_t* seeds, int32_t n_seeds, int32_t n_draws, int32_t* out)
+{
+    if (!ctx || !seeds || !out || n_seeds <= 0 || n_draws <= 0) return RT_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    unsigned int* d_seeds = nullptr; int* d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_seeds, sizeof(uint32_t) * n_seeds));
+    hipError_t e = hipMalloc((void**)&d_out, sizeof(int32_t) * (size_t)n_seeds * n_draws);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_seeds, seeds, sizeof(uint32_t) * n_seeds, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = rt_launch_debug_rand(d_seeds, n_seeds, n_draws, d_out, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(int32_t) * (size_t)n_seeds * n_draws, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_seeds); if (d_out) (void)hipFree(d_out);
+    HIP_TRY(ctx, e);
+    return RT_OK;
+}
+
+int rt_debug_quantise(rt_ctx* ctx, const float* in, int32_t n, uint8_t* out)
+{
+    if (!ctx || !in || !out || n <= 0) return RT_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    float* d_in = nullptr; unsigned char* d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_in, sizeof(float) * (size_t)n));
+    hipError_t e = hipMalloc((void**)&d_out, (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = rt_launch_debug_quantise(d_in, n, d_out, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in); if (d_out) (void)hipFree(d_out);
+    HIP_TRY(ctx, e);
+    return RT_OK;
+}
+
+int rt_debug_intersect(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays, float* out8)
+{
+    if (!ctx || !rays || !out8 || n_rays <= 0) return RT_ERR_INVALID_ARG;
+    if (!ctx->has_scene) return RT_ERR_NO_SCENE;
+    if (index < 0 || index >= ctx->n_hit) return RT_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    float* d_rays = nullptr; float* d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_rays, sizeof(float) * 6 * (size_t)n_rays));
+    hipError_t e = hipMalloc((void**)&d_out, sizeof(float) * 8 * (size_t)n_rays);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, sizeof(float) * 6 * (size_t)n_rays, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = rt_launch_debug_intersect(ctx->d_hrec, index, d_rays, n_rays, d_out, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out8, d_out, sizeof(float) * 8 * (size_t)n_rays, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_rays); if (d_out) (void)hipFree(d_out);
+    HIP_TRY(ctx, e);
+    return RT_OK;
+}
+
+}  // extern "C"

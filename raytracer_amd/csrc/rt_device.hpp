@@ -1,0 +1,339 @@
+// Device-side building blocks of the TraceRay hot path for gfx950 (wave64).  Everything here is float32 in the
+// reference's operation order (GLM 0.9.9.8 scalar mode); the translation unit is built with
+// -ffp-contract=off and HIP's default correctly-rounded fp32 divide/sqrt, so results are bit-identical to the x86
+// reference.  Reference citations are relative to the reference's src/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 mk(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ v3 operator-(v3 a) { return mk(-a.x, -a.y, -a.z); }
+// glm dot(vec3): tmp = a*b; tmp.x + tmp.y + tmp.z (vendor/glm/detail/func_geometric.inl:48-55)
+__device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// glm normalize = v * (1 / sqrt(dot(v,v))) (func_geometric.inl:88, func_exponential.inl:138)
+__device__ __forceinline__ v3 normalize(v3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+// glm reflect = I - N * dot(N,I) * 2 (func_geometric.inl:108)
+__device__ __forceinline__ v3 reflect(v3 I, v3 N) { return I - (N * dot(N, I)) * 2.0f; }
+// glm min/max (func_common.inl:20,29): NaN handling follows the comparisons, so no fminf/fmaxf here
+__device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
+__device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }
+__device__ __forceinline__ float clamp01(float x) { return gmin(gmax(x, 0.0f), 1.0f); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Scene image.  The host flattens the scene into these records (rt_abi.cpp), the kernel stages them into LDS once
+// per workgroup.  One hittable = two float4:
+//   r0 = (a.x, a.y, a.z, sphere: radius*radius)         a = sphere centre | plane centre | cube min corner
+//   r1 = (b.x, b.y, b.z, bits(type | material << 2))    b = plane unit normal | cube max corner (a + size)
+// radius*radius and a+size are the same float operations the reference performs per ray (sphere.h:19, cube.h:17).
+// One light = one float4 (v.xyz, bits(type)): v = normalize(-direction) (directionalLight.h:9) | position.
+// One material = 10 floats (material.h:5-11).
+enum { T_SPHERE = 0, T_PLANE = 1, T_CUBE = 2 };
+enum { L_DIR = 0, L_POINT = 1 };
+
+struct SceneLds {
+    const float4* hrec;   // 2 * n_hit
+    const float4* lights; // n_lights
+    const float*  mats;   // 10 * n_mat
+    int n_hit, n_lights;
+};
+
+struct Counters { unsigned int closest, shadow, tests, draws; };
+
+// ---------------------------------------------------------------------------------------------------------------
+// RNG: glibc srand()/rand() TYPE_3 additive-feedback generator (rand.h:7,9), one generator per
+// pixel.  State = 31 words in LDS, slot-major (word k of thread t at [k*BLOCK + t]) so a wave's access to one slot
+// hits 64 consecutive banks.  Seeding runs in registers (31 words, fully unrolled) and is lazy: most pixels of a
+// diffuse scene never draw.
+template <int BLOCK>
+struct Rng {
+    unsigned int* st;   // LDS base + thread index
+    int f, b;           // front / rear slot (glibc fptr / rptr)
+    bool seeded;
+    unsigned int seed;
+
+    __device__ __forceinline__ void init(unsigned int* lds_base, int tid, unsigned int s)
+    {
+        st = lds_base + tid; seed = s; seeded = false; f = 3; b = 0;
+    }
+
+    __device__ void do_seed()
+    {
+        unsigned int r[31];
+        unsigned int s = seed == 0u ? 1u : seed;
+        r[0] = s;
+        int word = (int)s;
+#pragma unroll
+        for (int i = 1; i < 31; ++i) {
+            // 16807 * word % 2147483647 without overflow (glibc random_r.c __srandom_r)
+            int hi = word / 127773;
+            int lo = word % 127773;
+            word = 16807 * lo - 2836 * hi;
+            if (word < 0) word += 2147483647;
+            r[i] = (unsigned int)word;
+        }
+        // discard 310 outputs: 10 full turns of r[(k+3)%31] += r[k]
+#pragma unroll 1
+        for (int turn = 0; turn < 10; ++turn) {
+#pragma unroll
+            for (int k = 0; k < 31; ++k) r[(k + 3) % 31] += r[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 31; ++k) st[k * BLOCK] = r[k];
+        f = 3; b = 0; seeded = true;
+    }
+
+    // one rand(): r[f] += r[b]; result = r[f] >> 1
+    __device__ __forceinline__ int next()
+    {
+        unsigned int v = st[f * BLOCK] + st[b * BLOCK];
+        st[f * BLOCK] = v;
+        f = (f == 30) ? 0 : f + 1;
+        b = (b == 30) ? 0 : b + 1;
+        return (int)(v >> 1);
+    }
+
+    // randomUnit() = (float)rand() / (float)RAND_MAX, (float)RAND_MAX == 2^31 (rand.h:9)
+    __device__ __forceinline__ float unit() { return (float)next() * 4.656612873077392578125e-10f; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Primitive tests.  Each returns whether the reference's intersect() would return true and, if so, hit.distance.
+// Position / normal are produced afterwards for the winning hittable only (same values: the reference overwrites
+// them on every accepted candidate, hittablesList.h:27-31).
+
+// sphere.h:13-44.  `a` = dot(dir,dir) and `fa` = 4*a are per-ray values.
+__device__ __forceinline__ bool sphere_hit(float4 r0, v3 ro, v3 rd, float fa, float& dist)
+{
+    v3 origin = ro - mk(r0.x, r0.y, r0.z);
+    float b = 2.0f * dot(origin, rd);
+    float c = dot(origin, origin) - r0.w;
+    float discriminant = b * b - fa * c;
+    if (discriminant < 0.0f) return false;
+    float sqrtd = sqrtf(discriminant);
+    float t1 = (-b - sqrtd) / 2.0f;
+    float t2 = (-b + sqrtd) / 2.0f;
+    if (t1 < 0 && t2 < 0) return false;
+    if (t2 > t1) dist = (t1 >= 0) ? t1 : t2;
+    else         dist = (t2 >= 0) ? t2 : t1;
+    return true;
+}
+
+// plane.h:13-23.  The reference compares |denom| against the double 1e-6; for a float x, (double)x <= 1e-6 is
+// the same as x <= (float)1e-6 because (float)1e-6 < 1e-6 ("epsilon compares").
+__device__ __forceinline__ bool plane_hit(float4 r0, float4 r1, v3 ro, v3 rd, float& dist)
+{
+    v3 n = mk(r1.x, r1.y, r1.z);
+    float denom = dot(n, rd);
+    if (fabsf(denom) <= 1e-6f) return false;
+    float t = dot(ro - mk(r0.x, r0.y, r0.z), n) / denom;
+    if (t < 0) return false;
+    dist = t;
+    return true;
+}
+
+// cube.h:13-28 (always tMin, even when negative).  inv = 1/dir per component, IEEE infinities included.
+__device__ __forceinline__ bool cube_hit(float4 r0, float4 r1, v3 ro, v3 inv, float& dist)
+{
+    v3 t0 = (mk(r0.x, r0.y, r0.z) - ro) * inv;
+    v3 t1 = (mk(r1.x, r1.y, r1.z) - ro) * inv;
+    v3 tmin = mk(gmin(t0.x, t1.x), gmin(t0.y, t1.y), gmin(t0.z, t1.z));
+    v3 tmax = mk(gmax(t0.x, t1.x), gmax(t0.y, t1.y), gmax(t0.z, t1.z));
+    float tMin = gmax(gmax(tmin.x, tmin.y), tmin.z);
+    float tMax = gmin(gmin(tmax.x, tmax.y), tmax.z);
+    if (tMax < 0 || tMin > tMax) return false;
+    dist = tMin;
+    return true;
+}
+
+__device__ __forceinline__ int rec_type(float4 r1) { return __float_as_int(r1.w) & 3; }
+__device__ __forceinline__ int rec_material(float4 r1) { return __float_as_int(r1.w) >> 2; }
+
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ bool hittable_hit(float4 r0, float4 r1, v3 ro, v3 rd, float fa, v3 inv, float& dist)
+{
+    if (HAS_NONSPHERE) {
+        // the record index is wave-uniform, so the type is too: make the branch scalar
+        int type = __builtin_amdgcn_readfirstlane(rec_type(r1));
+        if (type == T_PLANE) return plane_hit(r0, r1, ro, rd, dist);
+        if (type == T_CUBE)  return cube_hit(r0, r1, ro, inv, dist);
+    }
+    return sphere_hit(r0, ro, rd, fa, dist);
+}
+
+struct Hit { v3 position, normal; int material; };
+
+// position / normal / material of hittable `idx` at distance `dist` (sphere.h:46-49, plane.h:24-26, cube.h:28-46)
+__device__ __forceinline__ Hit hit_record(const SceneLds& sc, int idx, v3 ro, v3 rd, float dist)
+{
+    float4 r0 = sc.hrec[2 * idx], r1 = sc.hrec[2 * idx + 1];
+    int type = rec_type(r1);
+    Hit h;
+    h.material = rec_material(r1);
+    v3 a = mk(r0.x, r0.y, r0.z);
+    if (type == T_SPHERE) {
+        v3 origin = ro - a;
+        v3 p = origin + rd * dist;
+        h.normal = normalize(p);
+        h.position = p + a;
+    } else if (type == T_PLANE) {
+        h.position = ro + rd * dist;
+        h.normal = mk(r1.x, r1.y, r1.z);
+    } else {
+        v3 hp = ro + rd * dist;
+        // |x| < 1e-4 (double) <=> |x| <= (float)1e-4 for float x
+        v3 n;
+        if      (fabsf(hp.x - r0.x) <= 1e-4f) n = mk(-1, 0, 0);
+        else if (fabsf(hp.x - r1.x) <= 1e-4f) n = mk(1, 0, 0);
+        else if (fabsf(hp.y - r0.y) <= 1e-4f) n = mk(0, -1, 0);
+        else if (fabsf(hp.y - r1.y) <= 1e-4f) n = mk(0, 1, 0);
+        else if (fabsf(hp.z - r0.z) <= 1e-4f) n = mk(0, 0, -1);
+        else                                  n = mk(0, 0, 1);
+        h.position = hp;
+        h.normal = n;
+    }
+    return h;
+}
+
+// HittablesList::intersect (hittablesList.h:17-37): brute force, strict '<' so the earlier hittable wins ties;
+// a candidate replaces the best unless `dist >= best` (NaN distances therefore replace, as in the reference).
+template <bool HAS_NONSPHERE, bool COUNT>
+__device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, float& best, Counters& cnt)
+{
+    float fa = 4.0f * dot(rd, rd);
+    v3 inv = mk(0, 0, 0);
+    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    best = 3.402823466e+38f;   // FLT_MAX
+    int bi = -1;
+    for (int i = 0; i < sc.n_hit; ++i) {
+        float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+        float d;
+        if (COUNT) ++cnt.tests;
+        if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, d) && !(d >= best)) { best = d; bi = i; }
+    }
+    return bi;
+}
+
+// HittablesList::hasIntersect (hittablesList.h:39-50): first hittable whose intersect() is true, no distance bound.
+// With `limit`: the point-light occlusion test "some hittable is hit strictly closer than the light".
+template <bool HAS_NONSPHERE, bool COUNT, bool LIMITED>
+__device__ __forceinline__ bool any_hit(const SceneLds& sc, v3 ro, v3 rd, float limit, Counters& cnt)
+{
+    float fa = 4.0f * dot(rd, rd);
+    v3 inv = mk(0, 0, 0);
+    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    for (int i = 0; i < sc.n_hit; ++i) {
+        float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+        float d;
+        if (COUNT) ++cnt.tests;
+        if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, d)) {
+            if (!LIMITED || d < limit) return true;
+        }
+    }
+    return false;
+}
+
+// LightsList::GetLightIntensity (lightsList.h:22-40) over DirectionalLight (directionalLight.h:11-20) and the
+// repo-defined point light.  The reference asks IsInLight first and the Lambert term second; the result only
+// changes when the Lambert term exceeds the running maximum, so unless COUNT (tallies like the reference) the
+// occlusion query is skipped whenever it cannot matter.  Same value either way.
+template <bool HAS_NONSPHERE, bool COUNT>
+__device__ __forceinline__ float light_intensity(const SceneLds& sc, v3 position, v3 normal, Counters& cnt)
+{
+    float intensity = 0.085f;
+    for (int i = 0; i < sc.n_lights; ++i) {
+        float4 L = sc.lights[i];
+        int type = __builtin_amdgcn_readfirstlane(__float_as_int(L.w));
+        if (type == L_DIR) {
+            v3 l = mk(L.x, L.y, L.z);
+            float d = dot(normal, l);
+            float intens = d > 0 ? d : 0;
+            if (COUNT) {
+                ++cnt.shadow;
+                if (any_hit<HAS_NONSPHERE, COUNT, false>(sc, position, l, 0.0f, cnt)) continue;
+                if (intens > intensity) intensity = intens;
+            } else if (intens > intensity) {
+                if (!any_hit<HAS_NONSPHERE, COUNT, false>(sc, position, l, 0.0f, cnt)) intensity = intens;
+            }
+        } else {
+            v3 dv = mk(L.x, L.y, L.z) - position;
+            float dist = sqrtf(dot(dv, dv));
+            v3 l = normalize(dv);
+            float d = dot(normal, l);
+            float intens = d > 0 ? d : 0;
+            if (COUNT) {
+                ++cnt.shadow;
+                if (any_hit<HAS_NONSPHERE, COUNT, true>(sc, position, l, dist, cnt)) continue;
+                if (intens > intensity) intensity = intens;
+            } else if (intens > intensity) {
+                if (!any_hit<HAS_NONSPHERE, COUNT, true>(sc, position, l, dist, cnt)) intensity = intens;
+            }
+        }
+    }
+    return intensity;
+}
+
+// RANDOM_UNIT_EMISPHERE (core.h:24-35): three draws in x, y, z order, normalise, flip into the normal's hemisphere
+template <int BLOCK, bool COUNT>
+__device__ __forceinline__ v3 random_unit_hemisphere(Rng<BLOCK>& rng, v3 normal, Counters& cnt)
+{
+    if (!rng.seeded) rng.do_seed();
+    float x = rng.unit();
+    float y = rng.unit();
+    float z = rng.unit();
+    if (COUNT) cnt.draws += 3;
+    v3 rnd = normalize(mk(x, y, z));
+    if (dot(rnd, normal) > 0) return rnd;
+    return -rnd;
+}
+
+// refract (core.h:38-48)
+__device__ __forceinline__ bool refract_dir(v3 v, v3 n, float ir, v3& refracted)
+{
+    v3 uv = normalize(v);
+    float dt = dot(uv, n);
+    float discriminant = 1.0f - ir * ir * (1.0f - dt * dt);
+    if (discriminant <= 0) return false;
+    refracted = normalize((uv - n * dt) * ir - n * sqrtf(discriminant));
+    return true;
+}
+
+struct Camera {
+    float pos[3];
+    float ip[16];   // inverse projection, column major
+    float iv[16];   // inverse view, column major
+};
+
+// UVToDirection (renderer.h:21-25); mat4*vec4 = (m0*v0 + m1*v1) + (m2*v2 + m3*v3) (type_mat4x4.inl:561-572)
+__device__ __forceinline__ v3 uv_to_direction(const Camera& c, float u, float v)
+{
+    float t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        t[r] = (c.ip[r] * u + c.ip[4 + r] * v) + (c.ip[8 + r] * 1.0f + c.ip[12 + r] * 1.0f);
+    v3 n = normalize(mk(t[0] / t[3], t[1] / t[3], t[2] / t[3]));
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        d[r] = (c.iv[r] * n.x + c.iv[4 + r] * n.y) + (c.iv[8 + r] * n.z + c.iv[12 + r] * 0.0f);
+    return mk(d[0], d[1], d[2]);
+}
+
+// pixel::Set for one channel (structs.h:12-17): the unqualified sqrt is the double overload, * 255.0f is a double
+// multiply, the conversion truncates.  NaN -> 0 (what the x86 reference binary produces).
+__device__ __forceinline__ unsigned char quantise(float c)
+{
+    double d = sqrt((double)c) * 255.0;
+    if (!(d == d)) return 0;
+    return (unsigned char)(int)d;
+}
+
+}  // namespace rt

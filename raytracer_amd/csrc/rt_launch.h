@@ -1,0 +1,47 @@
+// Interface between the C-ABI layer (rt_abi.cpp) and the kernels (rt_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Bounce-stack capacities.  A path's frames are its ancestors: at most `max_depth` reflection parents (each adds
+// one to depth, renderer.h:68,82) plus the refraction parents, whose count is bounded by multiplier *= 0.9f until
+// < 0.001f (renderer.h:30,118): 66 in float arithmetic (rt_abi.cpp recomputes it).  Shallow serves max_depth <= 14,
+// deep serves RT_MAX_DEPTH (64).
+#define RT_STACK_SHALLOW 80
+#define RT_PEND_SHALLOW  15
+#define RT_STACK_DEEP    132
+#define RT_PEND_DEEP     65
+
+struct KernelArgs {
+    float cam[35];               // position, inverse projection, inverse view (rt_camera35f)
+    int width, height, samples, max_depth;
+    unsigned int seed_base;      // low 32 bits: srand() takes an unsigned int (rand.h:7)
+    int row0, rows, band_rows, band_stride;
+    int tiles_x, tiles_y;
+    int n_hit, n_lights, n_mat;
+    const float4* hrec;          // 2 * n_hit
+    const float4* lights;        // n_lights
+    const float* mats;           // 10 * n_mat
+    unsigned char* rgb;          // rows * width * 3 (probe: width * height flags)
+    float4* emission;            // rows * width, or null
+    unsigned long long* counters;// 4 words (closest, shadow, tests, draws), or null
+    int* fault;                  // set to 1 by a kernel whose bounce stack would overflow
+};
+
+struct LaunchTraits {
+    bool emission;   // emission buffer requested
+    bool mixed;      // some material has reflection > 0 and refraction > 0
+    bool nonsphere;  // scene holds planes or cubes
+    bool deep;       // max_depth needs the deep stack
+    bool count;      // tally like the reference
+};
+
+size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat);
+hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
+hipError_t rt_launch_probe(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
+hipError_t rt_launch_deinterleave(const void* gathered, void* frame, int row_bytes, int height, int band_rows,
+                                  int nranks, int rows_per_rank, hipStream_t stream);
+hipError_t rt_launch_debug_rand(const unsigned int* seeds, int n_seeds, int n_draws, int* out, hipStream_t stream);
+hipError_t rt_launch_debug_quantise(const float* in, int n, unsigned char* out, hipStream_t stream);
+hipError_t rt_launch_debug_intersect(const float4* hrec, int index, const float* rays, int n, float* out8, hipStream_t stream);

@@ -1,0 +1,144 @@
+"""Renderer: thin object wrapper over the C-ABI (rt_create / rt_upload_scene / rt_render_rows / ...)."""
+import ctypes
+
+import numpy as np
+
+from . import _abi
+from .scenes import Scene
+
+
+def camera35f(scene_or_fov=60.0, width=1024, height=512, znear=0.01, zfar=1000.0):
+    """rt_camera_init: Camera(fov, W, H, near, far) of the reference (src/camera.h:11-22) -> 35 float32."""
+    if isinstance(scene_or_fov, Scene):
+        fov, znear, zfar = scene_or_fov.fov, scene_or_fov.znear, scene_or_fov.zfar
+    else:
+        fov = scene_or_fov
+    cam = _abi.Camera35f()
+    rc = _abi.load().rt_camera_init(ctypes.byref(cam), fov, float(width), float(height), znear, zfar)
+    if rc != _abi.RT_OK:
+        raise _abi.RtError(rc, "rt_camera_init")
+    return cam
+
+
+def camera_array(cam):
+    return np.frombuffer(bytes(cam), dtype=np.float32).copy()
+
+
+def _ptr(buf):
+    """host numpy array or torch tensor (host or device) -> raw address"""
+    if buf is None:
+        return None
+    if isinstance(buf, np.ndarray):
+        assert buf.flags["C_CONTIGUOUS"]
+        return buf.ctypes.data
+    if hasattr(buf, "data_ptr"):
+        assert buf.is_contiguous()
+        return buf.data_ptr()
+    raise TypeError("expected a numpy array or a torch tensor")
+
+
+class Renderer:
+    """One context on one GPU (not thread-safe, synchronous calls), mirroring the C-ABI one to one."""
+
+    def __init__(self, device=0):
+        self._lib = _abi.load()
+        h = ctypes.c_void_p()
+        rc = self._lib.rt_create(ctypes.byref(h), int(device))
+        if rc != _abi.RT_OK:
+            raise _abi.RtError(rc, "rt_create")
+        self._h = h
+        self.device = int(device)
+        self.scene = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != _abi.RT_OK:
+            raise _abi.RtError(rc, what, self._lib.rt_last_hip_error(self._h))
+
+    def upload_scene(self, scene: Scene):
+        mats, htype, ha, hb, hr, hm, ltype, lv = (np.ascontiguousarray(a) for a in scene.arrays())
+        soa = _abi.SceneSoA(len(mats), mats.ctypes.data, len(htype), htype.ctypes.data, ha.ctypes.data, hb.ctypes.data,
+                            hr.ctypes.data, hm.ctypes.data, len(ltype), ltype.ctypes.data, lv.ctypes.data)
+        self._check(self._lib.rt_upload_scene(self._h, ctypes.byref(soa)), "rt_upload_scene")
+        self.scene = scene
+
+    def params(self, width, height, samples, max_depth, seed_base=0, row0=0, rows=None, band_rows=0, band_stride=0, flags=0):
+        rows = height - row0 if rows is None else rows
+        return _abi.Params(width, height, samples, max_depth, seed_base, row0, rows, band_rows, band_stride, flags)
+
+    def render_rows(self, cam, params, rgb_out=None, emission_out=None, count=False):
+        """rt_render_rows into caller buffers (numpy = host, torch cuda tensor = device).  -> counters dict or None"""
+        cnt = _abi.Counters()
+        if count:
+            params = _abi.Params.from_buffer_copy(params)
+            params.flags |= _abi.RT_FLAG_COUNT_LIKE_REFERENCE
+        rc = self._lib.rt_render_rows(self._h, ctypes.byref(cam), ctypes.byref(params), _ptr(rgb_out), _ptr(emission_out),
+                                      ctypes.byref(cnt) if count else None)
+        self._check(rc, "rt_render_rows")
+        if count:
+            return {k: int(getattr(cnt, k)) for k in ("primary", "closest", "shadow", "tests", "rand_draws")}
+        return None
+
+    def render(self, width, height, samples, max_depth, seed_base=0, emission=False, count=False, cam=None, **rows):
+        """Convenience: whole frame (or the rows selected by row0/rows/band_rows/band_stride) into fresh host arrays.
+        -> (rgb uint8 [rows, W, 3], emission float32 [rows, W, 4] or None, counters or None)"""
+        p = self.params(width, height, samples, max_depth, seed_base, **rows)
+        cam = cam or camera35f(self.scene, width, height)
+        rgb = np.zeros((p.rows, width, 3), dtype=np.uint8)
+        em = np.zeros((p.rows, width, 4), dtype=np.float32) if emission else None
+        cnt = self.render_rows(cam, p, rgb, em, count=count)
+        return rgb, em, cnt
+
+    def probe_max_depth(self, width, height, max_depth, seed_base=0, cam=None):
+        p = self.params(width, height, 1, max_depth, seed_base)
+        cam = cam or camera35f(self.scene, width, height)
+        flags = np.zeros((height, width), dtype=np.uint8)
+        self._check(self._lib.rt_probe_max_depth(self._h, ctypes.byref(cam), ctypes.byref(p), flags.ctypes.data), "rt_probe_max_depth")
+        return flags
+
+    def deinterleave_bands(self, gathered, frame_out, width, height, bytes_per_pixel, band_rows, nranks, rows_per_rank):
+        self._check(self._lib.rt_deinterleave_bands(self._h, _ptr(gathered), _ptr(frame_out), width, height, bytes_per_pixel,
+                                                    band_rows, nranks, rows_per_rank), "rt_deinterleave_bands")
+
+    @property
+    def last_kernel_ms(self):
+        return float(self._lib.rt_last_kernel_ms(self._h))
+
+    # unit-test hooks
+    def debug_rand(self, seeds, n_draws):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        out = np.zeros((len(seeds), n_draws), dtype=np.int32)
+        self._check(self._lib.rt_debug_rand(self._h, seeds.ctypes.data, len(seeds), n_draws, out.ctypes.data), "rt_debug_rand")
+        return out
+
+    def debug_quantise(self, values):
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        out = np.zeros(len(values), dtype=np.uint8)
+        self._check(self._lib.rt_debug_quantise(self._h, values.ctypes.data, len(values), out.ctypes.data), "rt_debug_quantise")
+        return out
+
+    def debug_intersect(self, index, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        out = np.zeros((len(rays), 8), dtype=np.float32)
+        self._check(self._lib.rt_debug_intersect(self._h, index, rays.ctypes.data, len(rays), out.ctypes.data), "rt_debug_intersect")
+        return out
+
+
+def write_ppm(path, rgb):
+    """P6 writer with the reference's header (src/main.cpp:423)."""
+    h, w, _ = rgb.shape
+    with open(path, "wb") as fh:
+        fh.write(b"P6\n%d %d\n255\n" % (w, h))
+        fh.write(np.ascontiguousarray(rgb, dtype=np.uint8).tobytes())

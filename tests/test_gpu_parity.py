@@ -1,0 +1,256 @@
+"""GPU parity: the HIP path through the C-ABI against (1) the committed golden fixtures produced by the real
+reference and (2) the CPU oracle on the same seeded inputs.  Bar: images byte-identical, emission buffers
+bit-identical, query counters equal (float32 arithmetic is reproduced operation for operation, so the north-star
+tolerance of >=99.9 % pixels within 1 LSB / >=50 dB PSNR is met with zero differing pixels)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import raytracer_amd as ra
+from raytracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("probe_"))
+
+
+@pytest.fixture(scope="module")
+def rt():
+    r = ra.Renderer(0)
+    yield r
+    r.close()
+
+
+def load_case(path):
+    z = np.load(path)
+    sc = scenes.Scene.from_text(bytes(z["scene"]).decode())
+    W, H, samples, depth, seed = (int(v) for v in z["params"])
+    return z, sc, W, H, samples, depth, seed
+
+
+def report(name, got, want):
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32)).max(axis=-1)
+    n_bad = int((diff > 1).sum())
+    mse = float(((got.astype(np.float64) - want.astype(np.float64)) ** 2).mean())
+    psnr = float("inf") if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+    print("%s: differing pixels %d, >1 LSB %d of %d, PSNR %.1f dB" % (name, int((diff > 0).sum()), n_bad, diff.size, psnr))
+    return n_bad, psnr
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_matches_reference_golden(rt, path):
+    z, sc, W, H, samples, depth, seed = load_case(path)
+    rt.upload_scene(sc)
+    rgb, em, _ = rt.render(W, H, samples, depth, seed, emission=True)
+    report(os.path.basename(path), rgb, z["rgb"])
+    assert np.array_equal(rgb, z["rgb"])
+    assert np.array_equal(em.view(np.uint32), z["emission"].view(np.uint32))
+    # the rgb-only kernel variant (no emission bookkeeping) must give the same image
+    rgb2, _, _ = rt.render(W, H, samples, depth, seed, emission=False)
+    assert np.array_equal(rgb2, z["rgb"])
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_counters_match_reference(rt, path):
+    z, sc, W, H, samples, depth, seed = load_case(path)
+    rt.upload_scene(sc)
+    rgb, em, cnt = rt.render(W, H, samples, depth, seed, emission=True, count=True)
+    assert [cnt[k] for k in ("primary", "closest", "shadow", "tests", "rand_draws")] == [int(v) for v in z["counters"]]
+    assert np.array_equal(rgb, z["rgb"]) and np.array_equal(em.view(np.uint32), z["emission"].view(np.uint32))
+
+
+def test_camera_bits_match_reference(golden_dir):
+    import json
+    from raytracer_amd.renderer import camera_array
+    with open(os.path.join(golden_dir, "camera_bits.json")) as fh:
+        cams = json.load(fh)
+    for key, bits in cams.items():
+        W, H = (int(v) for v in key.split("x"))
+        assert [int(b) for b in camera_array(ra.camera35f(60.0, W, H)).view(np.uint32)] == bits, key
+
+
+@pytest.mark.parametrize("name,W,H,samples,depth,seed", [
+    ("default4", 333, 77, 3, 10, 123456789),        # ragged: width and height not multiples of the 16x16 tile
+    ("default4", 17, 1, 2, 10, 0),                  # one row
+    ("default4", 1, 19, 2, 4, 5),                   # one column
+    ("glass_mirror", 200, 120, 3, 5, 77),
+    ("glass_mirror", 64, 64, 2, 20, 1),             # deep stack variant (max_depth > 14)
+    ("degenerate", 200, 120, 3, 64, 77),            # RT_MAX_DEPTH
+    ("random10", 256, 128, 4, 12, 0),
+    ("cube", 200, 120, 3, 5, 77),
+    ("plane", 200, 120, 3, 5, 77),
+    ("pointlights", 96, 64, 2, 6, 5),
+])
+def test_matches_oracle_on_seeded_inputs(rt, name, W, H, samples, depth, seed):
+    sc = scenes.BUILTIN[name]()
+    want_rgb, want_em, want_cnt = oracle_lib.render(sc, W, H, samples, depth, seed, threads=8)
+    rt.upload_scene(sc)
+    rgb, em, cnt = rt.render(W, H, samples, depth, seed, emission=True, count=True)
+    report(name, rgb, want_rgb)
+    assert np.array_equal(rgb, want_rgb)
+    assert np.array_equal(em.view(np.uint32), want_em.view(np.uint32))
+    assert cnt == want_cnt
+    rgb2, _, _ = rt.render(W, H, samples, depth, seed)
+    assert np.array_equal(rgb2, want_rgb)
+
+
+def test_many_objects_small(rt):
+    sc = scenes.many_objects(n=300, n_lights=8, seed=11)
+    W, H, samples, depth, seed = 96, 48, 1, 5, 2
+    want_rgb, want_em, want_cnt = oracle_lib.render(sc, W, H, samples, depth, seed, threads=8)
+    rt.upload_scene(sc)
+    rgb, em, cnt = rt.render(W, H, samples, depth, seed, emission=True, count=True)
+    assert np.array_equal(rgb, want_rgb) and np.array_equal(em.view(np.uint32), want_em.view(np.uint32)) and cnt == want_cnt
+
+
+def test_rows_and_cyclic_bands_are_partition_independent(rt):
+    sc = scenes.glass_mirror()
+    W, H, samples, depth, seed = 120, 100, 2, 6, 9
+    rt.upload_scene(sc)
+    full, full_em, _ = rt.render(W, H, samples, depth, seed, emission=True)
+    # contiguous slabs
+    top, _, _ = rt.render(W, H, samples, depth, seed, row0=0, rows=37)
+    bot, _, _ = rt.render(W, H, samples, depth, seed, row0=37, rows=H - 37)
+    assert np.array_equal(np.concatenate([top, bot]), full)
+    # cyclic bands of 8 rows over 3 ranks (H = 100 is not a multiple of 24: the last turn is ragged)
+    band, nranks = 8, 3
+    frame = np.zeros_like(full)
+    for rank in range(nranks):
+        ys = [y for y in range(H) if (y // band) % nranks == rank]
+        rgb, _, _ = rt.render(W, H, samples, depth, seed, row0=rank * band, rows=len(ys), band_rows=band, band_stride=band * nranks)
+        frame[ys] = rgb
+    assert np.array_equal(frame, full)
+
+
+def test_device_output_buffers_and_deinterleave(rt):
+    import torch
+    sc = scenes.default4()
+    W, H, samples, depth, seed = 128, 72, 2, 10, 0
+    rt.upload_scene(sc)
+    full, full_em, _ = rt.render(W, H, samples, depth, seed, emission=True)
+    band, nranks = 8, 2
+    nbands = (H + band - 1) // band
+    rows_per_rank = ((nbands + nranks - 1) // nranks) * band
+    gathered = torch.zeros((nranks, rows_per_rank, W, 3), dtype=torch.uint8, device="cuda:0")
+    gathered_em = torch.zeros((nranks, rows_per_rank, W, 4), dtype=torch.float32, device="cuda:0")
+    cam = ra.camera35f(sc, W, H)
+    for rank in range(nranks):
+        nrows = sum(1 for y in range(H) if (y // band) % nranks == rank)
+        p = rt.params(W, H, samples, depth, seed, row0=rank * band, rows=nrows, band_rows=band, band_stride=band * nranks)
+        rt.render_rows(cam, p, gathered[rank], gathered_em[rank])
+    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    frame_em = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    rt.deinterleave_bands(gathered, frame, W, H, 3, band, nranks, rows_per_rank)
+    rt.deinterleave_bands(gathered_em, frame_em, W, H, 16, band, nranks, rows_per_rank)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), full)
+    assert np.array_equal(frame_em.cpu().numpy().view(np.uint32), full_em.view(np.uint32))
+
+
+def test_probe_max_depth(rt, golden_dir):
+    z = np.load(os.path.join(golden_dir, "probe_glass_mirror_128x64_d3_seed0.npz"))
+    sc = scenes.Scene.from_text(bytes(z["scene"]).decode())
+    W, H, _, depth, seed = (int(v) for v in z["params"])
+    rt.upload_scene(sc)
+    assert np.array_equal(rt.probe_max_depth(W, H, depth, seed), z["flags"])
+
+
+def test_rng_reproduces_glibc(rt, golden_dir):
+    import json
+    with open(os.path.join(golden_dir, "glibc_rand.json")) as fh:
+        known = json.load(fh)
+    seeds = [int(s) for s in known]
+    out = rt.debug_rand(seeds, 96)
+    for i, s in enumerate(seeds):
+        assert out[i].tolist() == known[str(s)], s
+    rs = np.random.RandomState(3)
+    seeds = rs.randint(0, 2**32, size=1000, dtype=np.uint64).astype(np.uint32)
+    out = rt.debug_rand(seeds, 40)
+    for i in range(0, 1000, 37):
+        assert out[i].tolist() == oracle_lib.rand_sequence(int(seeds[i]), 40)
+
+
+def test_quantise_matches_double_sqrt(rt):
+    rs = np.random.RandomState(5)
+    vals = [rs.uniform(0, 1, 200000).astype(np.float32), np.linspace(0, 1, 65537, dtype=np.float32)]
+    # floats on either side of every 8-bit boundary q: c = (q / 255)^2
+    q = np.arange(0, 256, dtype=np.float64)
+    edge = ((q / 255.0) ** 2).astype(np.float32)
+    for k in range(-3, 4):
+        e = edge.copy()
+        for _ in range(abs(k)):
+            e = np.nextafter(e, np.float32(2.0 if k > 0 else -1.0))
+        vals.append(np.clip(e, 0, 1))
+    vals.append(np.asarray([np.nan, 0.0, 1.0], dtype=np.float32))
+    v = np.concatenate(vals)
+    got = rt.debug_quantise(v)
+    with np.errstate(invalid="ignore"):
+        want = np.where(np.isnan(v), 0, (np.sqrt(v.astype(np.float64)) * 255.0)).astype(np.int64).astype(np.uint8)
+    assert np.array_equal(got, want)
+
+
+def test_primitive_known_answers(rt):
+    s = scenes.Scene()
+    s.material((1, 1, 1), 0, 0, 0)
+    s.sphere((0, 0, -5), 1.0, 0)
+    s.plane((0, 0, 0), (0, 1, 0), 0)
+    s.cube((-1, -1, -6), (2, 2, 2), 0)
+    rt.upload_scene(s)
+    # sphere.h: unit-direction ray along -z from the origin hits the unit sphere at z=-5 at distance 4, normal +z
+    o = rt.debug_intersect(0, [[0, 0, 0, 0, 0, -1], [0, 0, 0, 0, 0, 1], [0, 0, -5, 0, 0, -1], [0, 2, 0, 0, 0, -1]])
+    assert o[0].tolist() == [1, 4, 0, 0, -4, 0, 0, 1]
+    assert o[1][0] == 0                       # both roots negative
+    assert o[2].tolist() == [1, 1, 0, 0, -6, 0, 0, -1]   # origin inside: far root, outward normal
+    assert o[3][0] == 0                       # discriminant < 0
+    # sphere.h:26-27 does not divide by a: with direction (0,0,-2) t = 8 (not 2) and the "hit" lands at z = -16
+    o = rt.debug_intersect(0, [[0, 0, 0, 0, 0, -2]])
+    assert o[0][0] == 1 and o[0][1] == 8.0 and o[0][4] == -16.0
+    # plane.h:19 sign quirk: a ray going down towards y=0 from above gets t < 0 (miss); going up it "hits"
+    o = rt.debug_intersect(1, [[0, 1, 0, 0, -1, 0], [0, 1, 0, 0, 1, 0], [0, 1, 0, 1, 0, 0]])
+    assert o[0][0] == 0
+    assert o[1].tolist() == [1, 1, 0, 2, 0, 0, 1, 0]
+    assert o[2][0] == 0                       # |denom| <= 1e-6
+    # cube.h: slab test, always tMin; axis-parallel rays rely on IEEE infinities
+    o = rt.debug_intersect(2, [[0, 0, 0, 0, 0, -1], [0, 0, -5, 0, 0, -1], [5, 0, 0, 0, 0, -1]])
+    assert o[0].tolist() == [1, 4, 0, 0, -4, 0, 0, 1]
+    assert o[1][0] == 1 and o[1][1] == -1.0   # origin inside: negative tMin is returned as the distance
+    assert o[2][0] == 0
+
+
+def test_error_codes(rt):
+    from raytracer_amd import _abi
+    sc = scenes.default4()
+    rt.upload_scene(sc)
+    with pytest.raises(ra.RtError) as e:
+        rt.render(64, 64, 1, 65)                       # max_depth > RT_MAX_DEPTH
+    assert e.value.status == _abi.RT_ERR_UNSUPPORTED
+    with pytest.raises(ra.RtError) as e:
+        rt.render(64, 64, 0, 5)
+    assert e.value.status == _abi.RT_ERR_INVALID_ARG
+    with pytest.raises(ra.RtError) as e:
+        rt.render(64, 64, 1, 5, row0=60, rows=10)      # rows outside the frame
+    assert e.value.status == _abi.RT_ERR_INVALID_ARG
+    bad = scenes.default4(); bad.hittables[1] = (0, (0.0, 1.0, -4.0), (0.0, 0.0, 0.0), 1.0, 9)
+    with pytest.raises(ra.RtError) as e:
+        rt.upload_scene(bad)
+    assert e.value.status == _abi.RT_ERR_SCENE
+    hot = scenes.default4(); hot.materials[2] = hot.materials[2][:4] + (1.5,) + hot.materials[2][5:]
+    with pytest.raises(ra.RtError) as e:
+        rt.upload_scene(hot)
+    assert e.value.status == _abi.RT_ERR_UNSUPPORTED
+    fresh = ra.Renderer(0)
+    with pytest.raises(ra.RtError) as e:
+        fresh.render(64, 64, 1, 5, cam=ra.camera35f(60.0, 64, 64))
+    assert e.value.status == _abi.RT_ERR_NO_SCENE
+    fresh.close()
+    # empty scene and zero rows are legal
+    empty = scenes.Scene(); rt.upload_scene(empty)
+    rgb, _, _ = rt.render(32, 16, 1, 5)
+    want, _, _ = oracle_lib.render(empty, 32, 16, 1, 5)
+    assert np.array_equal(rgb, want)
+    rgb, _, _ = rt.render(32, 16, 1, 5, row0=3, rows=0)
+    assert rgb.shape == (0, 32, 3)
