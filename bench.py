@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + secondary closest-hit queries) of the TraceRay hot path.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step renders one whole frame of the workload: every rank renders its cyclic row bands with rt_render_rows into a
+device buffer, the bands are gathered to rank 0 (RCCL) and reassembled there.  N = 1 workload: BASELINE.json's metric
+configuration, DEFAULT-4 at 3840x2160, 64 spp, max depth 10 (it fits one GPU).  The frame is fixed, so scaling is
+"strong".  Ray counts are exact: the counting build of the kernel tallies closest-hit queries for the same frame
+outside the timed region (they equal the reference's, tests/test_gpu_parity.py).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene builder name, W, H, samples, max_depth)
+    "default4_4k_64spp": ("default4", 3840, 2160, 64, 10),       # BASELINE.json configs[2] / metric
+    "default4_1080p_16spp": ("default4", 1920, 1080, 16, 5),     # configs[1]
+    "default4_1024x512_5spp": ("default4", 1024, 512, 5, 10),    # configs[0]
+    "many2048_1080p_32spp": ("many_objects", 1920, 1080, 32, 10),  # configs[3]
+    "glass_1080p_64spp": ("glass_mirror", 1920, 1080, 64, 12),   # configs[4]
+}
+PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+BAND_ROWS = 16
+
+
+def algorithmic_flops(cnt, scene, n_pixels, samples):
+    """SURVEY.md section 8(d) per-op table applied to the tallies of the kernel's counting build (executed work):
+    ray generation 71 + per-ray accumulate 10; primitive test 30 sphere / 14 plane / 28 cube (type-weighted by the
+    scene's mix, exact for single-type scenes); per shaded hit: epilogue 19 + shade 17 + 6 per light; sky 15;
+    bounce 76 (the cheaper of reflection 76 / refraction 95, the tallies do not split them); per-sample clamp/add 19;
+    per-pixel finish 9."""
+    types = [h[0] for h in scene.hittables]
+    per_test = (30.0 * types.count(0) + 14.0 * types.count(1) + 28.0 * types.count(2)) / max(len(types), 1)
+    n_lights = max(len(scene.lights), 1)
+    hits = cnt["shaded"]
+    sky = cnt["closest"] - hits
+    bounces = cnt["rand_draws"] / 3.0
+    return (81.0 * cnt["primary"] + per_test * cnt["tests"] + hits * (19.0 + 17.0 + 6.0 * n_lights) + 15.0 * sky +
+            76.0 * bounces + 19.0 * n_pixels * samples + 9.0 * n_pixels)
+
+
+def cpu_baseline(scene, W, H, depth, closest_per_primary, budget_s=20.0):
+    """Times the reference's own multi-threaded renderer (oracle/_ref/ref_oracle: unmodified reference headers + its
+    ThreadPool, 16x16 tiles) on this box's host cores, on a bounded sample: the same frame at reduced spp (rays/s
+    does not depend on spp).  Falls back to the plain-C port when the reference binary is absent."""
+    cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))) - 1)   # hardware_concurrency()-1, main.cpp:268
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_oracle")
+    port = os.path.join(ROOT, "oracle", "rt_oracle")
+    if not os.path.exists(port):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "port"], check=True, capture_output=True)
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        sp = os.path.join(td, "scene.rtscene")
+        scene.save(sp)
+        for kind, exe in (("reference", ref), ("port", port)):
+            if not os.path.exists(exe):
+                continue
+            spp = 1
+            best = None
+            t_start = time.time()
+            while True:
+                r = subprocess.run([exe, "--scene", sp, "--w", str(W), "--h", str(H), "--samples", str(spp), "--depth", str(depth),
+                                    "--seed-base", "0", "--threads", str(cores)], capture_output=True, text=True, check=True)
+                info = json.loads(r.stdout.strip().splitlines()[-1])
+                rays = W * H * spp * 4 * closest_per_primary
+                best = {"value": rays / (info["ms"] * 1e-3) / 1e6, "ms": info["ms"], "spp": spp}
+                if info["ms"] > 2000.0 or time.time() - t_start > budget_s / 2 or spp >= 64:
+                    break
+                spp *= 4
+            out[kind] = best
+    kind = "reference" if "reference" in out else "port"
+    res = {"value": round(out[kind]["value"], 3), "unit": "Mrays/s", "cores": cores, "kind": kind,
+           "sample": "same scene and %dx%d frame at %d spp (%.0f ms), 16x16 tiles on %d worker threads" % (W, H, out[kind]["spp"], out[kind]["ms"], cores)}
+    if kind == "reference" and "port" in out:
+        res["port_value"] = round(out["port"]["value"], 3)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="default4_4k_64spp", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as ra
+    from raytracer_amd import bands
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene_name, W, H, samples, depth = WORKLOADS[args.workload]
+    scene = ra.scenes.BUILTIN[scene_name]()
+    seed = 0
+    rt = ra.Renderer(local_rank)
+    rt.upload_scene(scene)
+    cam = ra.camera35f(scene, W, H)
+    rpr = bands.rows_per_rank(H, BAND_ROWS, world)
+    p = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank)
+    block = torch.zeros((rpr, W, 3), dtype=torch.uint8, device=dev)
+
+    def step():
+        rt.render_rows(cam, p, block)
+        return bands.gather_frame(block, H, BAND_ROWS, rt)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame = step()
+        kernel_ms.append(rt.last_kernel_ms)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # exact tallies of this frame (untimed): counting build with the production kernel's shadow-query pruning
+    from raytracer_amd import _abi
+    pc = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank)
+    cnt = rt.render_rows(cam, pc, block, count=True, executed=True)
+    keys = ("primary", "closest", "shadow", "tests", "rand_draws", "shaded")
+    tv = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device=dev)
+    local_flops = algorithmic_flops(cnt, scene, W * p.rows, samples)
+    lf = torch.tensor([local_flops, float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tv)
+        mx = lf.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lf)
+        flops, kms = float(lf[0].item()), float(mx[1].item())
+    else:
+        flops, kms = float(lf[0].item()), float(lf[1].item())
+    tot = dict(zip(keys, (int(v) for v in tv.tolist())))
+
+    if rank == 0:
+        rays = tot["closest"]                       # primary + secondary closest-hit queries (renderer.h:40)
+        sec_per_step = elapsed / args.steps
+        value = rays / sec_per_step / 1e6
+        achieved = flops / (kms * 1e-3) / 1e12 / world       # per GPU: slowest rank's kernel time
+        line = {
+            "metric": "Mrays/s (primary+secondary) at 4K/64spp; % FP32 VALU peak",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp": samples, "max_depth": depth,
+                       "seed_base": seed, "parallelism": "cyclic %d-row bands over %d GPU(s), RCCL gather to rank 0" % (BAND_ROWS, world)},
+            "rays": {"primary": tot["primary"], "secondary": tot["closest"] - tot["primary"], "shadow_executed": tot["shadow"],
+                     "primitive_tests_executed": tot["tests"], "rng_draws": tot["rand_draws"]},
+            "kernel_ms": round(kms, 3),
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "note": "algorithmic FP32 flops (SURVEY 8d table x executed tallies) / kernel time from HIP events; "
+                                 "no FMA contraction (bit parity), so 0.5 is the ceiling of this definition; "
+                                 "VALU issue utilisation from PMC counters is in profiles/"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(scene, W, H, depth, tot["closest"] / tot["primary"])
+        print(json.dumps(line), flush=True)
+    rt.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

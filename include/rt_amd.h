@@ -92,13 +92,16 @@ typedef struct {
     int32_t flags;               /* RT_FLAG_* */
 } rt_params;
 
-#define RT_FLAG_COUNT_LIKE_REFERENCE 1  /* count every shadow query the reference would issue (slower kernel) */
+#define RT_FLAG_COUNT_LIKE_REFERENCE 1  /* tally, issuing every shadow query the reference would issue (slower)  */
+#define RT_FLAG_COUNT_EXECUTED       2  /* tally the production kernel's own work (shadow queries that cannot
+                                           change the pixel are skipped)                          */
 
 /* Query tallies with the reference's meaning: primary = W*rows*samples*4; closest = TraceRay closest-hit queries
  * (src/renderer.h:40); shadow = hasIntersect / point-light occlusion queries (directionalLight.h:13); tests =
- * primitive intersect() calls; rand_draws = RANDOM_UNIT calls.  Filled only with RT_FLAG_COUNT_LIKE_REFERENCE. */
+ * primitive intersect() calls; rand_draws = RANDOM_UNIT calls; shaded = closest-hit queries that hit (one
+ * GetLightIntensity each, src/renderer.h:58).  Filled only when one of the RT_FLAG_COUNT_* flags is set. */
 typedef struct {
-    uint64_t primary, closest, shadow, tests, rand_draws;
+    uint64_t primary, closest, shadow, tests, rand_draws, shaded;
 } rt_counters;
 
 /* Creates a context on GPU `device_ordinal` (HIP ordinal).  Replaces the cudaMalloc/cudaDeviceSetLimit set-up of
@@ -115,7 +118,7 @@ int rt_camera_init(rt_camera35f* cam, float fov_deg, float width, float height, 
 
 /* The hot path: replaces the tile lambda of src/main.cpp:289-330 (== the `kernel` of src/main.cu:38-67) for the
  * selected rows.  rgb_out: rows*width*3 bytes of `pixel` (src/structs.h:8-25), emission_out: rows*width*4 floats
- * of `emissionPixel` (src/structs.h:28-44) or NULL, counters: NULL unless RT_FLAG_COUNT_LIKE_REFERENCE.
+ * of `emissionPixel` (src/structs.h:28-44) or NULL, counters: NULL unless a RT_FLAG_COUNT_* flag is set.
  * rgb_out / emission_out may be host or device pointers (device pointers must belong to the context's GPU). */
 int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* params,
                    uint8_t* rgb_out, float* emission_out, rt_counters* counters);

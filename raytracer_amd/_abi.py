@@ -10,6 +10,7 @@ RT_OK = 0
 RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_SCENE = -1, -2, -3, -4
 RT_ERR_UNSUPPORTED, RT_ERR_NO_SCENE, RT_ERR_DEVICE_FAULT = -5, -6, -7
 RT_FLAG_COUNT_LIKE_REFERENCE = 1
+RT_FLAG_COUNT_EXECUTED = 2
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_probe_max_depth",
@@ -37,7 +38,7 @@ class Params(ctypes.Structure):
 
 
 class Counters(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_uint64) for k in ("primary", "closest", "shadow", "tests", "rand_draws")]
+    _fields_ = [(k, ctypes.c_uint64) for k in ("primary", "closest", "shadow", "tests", "rand_draws", "shaded")]
 
 
 class RtError(RuntimeError):

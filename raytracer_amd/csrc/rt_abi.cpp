@@ -34,6 +34,9 @@ struct rt_ctx {
     void* d_stage_em = nullptr;  size_t stage_em_bytes = 0;
 };
 
+// device words: 5 tallies (u64) followed by the fault flag
+#define RT_DEV_WORDS_BYTES (5 * sizeof(unsigned long long) + sizeof(int) * 2)
+
 #define HIP_TRY(ctx, expr)                                   \
     do {                                                     \
         hipError_t e__ = (expr);                             \
@@ -144,9 +147,9 @@ int rt_create(rt_ctx** out, int device_ordinal)
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 4 * sizeof(unsigned long long) + sizeof(int) * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, RT_DEV_WORDS_BYTES);
     if (e != hipSuccess) { rt_destroy(ctx); return RT_ERR_HIP; }
-    ctx->d_fault = (int*)(ctx->d_counters + 4);
+    ctx->d_fault = (int*)(ctx->d_counters + 5);
     *out = ctx;
     return RT_OK;
 }
@@ -271,7 +274,7 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
 {
     int rc = check_params(ctx, cam, p);
     if (rc != RT_OK) return rc;
-    const bool count = (p->flags & RT_FLAG_COUNT_LIKE_REFERENCE) != 0;
+    const bool count = (p->flags & (RT_FLAG_COUNT_LIKE_REFERENCE | RT_FLAG_COUNT_EXECUTED)) != 0;
     if (count && !counters) return RT_ERR_INVALID_ARG;
     if (!rgb_out && !emission_out && !count) return RT_ERR_INVALID_ARG;
     if (counters) std::memset(counters, 0, sizeof(*counters));
@@ -299,26 +302,27 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     t.mixed = ctx->mixed;
     t.nonsphere = ctx->nonsphere;
     t.count = count;
+    t.prune = (p->flags & RT_FLAG_COUNT_LIKE_REFERENCE) == 0;
     // frames on the bounce stack <= reflection parents (max_depth) + refraction parents (66)
     t.deep = refraction_chain_bound() + p->max_depth > RT_STACK_SHALLOW || p->max_depth > RT_PEND_SHALLOW - 1;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long) + sizeof(int) * 2, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_DEV_WORDS_BYTES, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(ctx, rt_launch_render(a, t, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 
     if (rgb_out && !rgb_dev) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, a.rgb, npix * 3, hipMemcpyDeviceToHost, ctx->stream));
     if (emission_out && !em_dev) HIP_TRY(ctx, hipMemcpyAsync(emission_out, a.emission, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
-    unsigned long long words[5] = { 0, 0, 0, 0, 0 };
+    unsigned long long words[6] = { 0, 0, 0, 0, 0, 0 };
     HIP_TRY(ctx, hipMemcpyAsync(words, ctx->d_counters, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
 
-    int fault; std::memcpy(&fault, &words[4], sizeof(int));
+    int fault; std::memcpy(&fault, &words[5], sizeof(int));
     if (fault) return RT_ERR_DEVICE_FAULT;
     if (count) {
         counters->primary = (uint64_t)npix * (uint64_t)p->samples * 4u;
-        counters->closest = words[0]; counters->shadow = words[1]; counters->tests = words[2]; counters->rand_draws = words[3];
+        counters->closest = words[0]; counters->shadow = words[1]; counters->tests = words[2]; counters->rand_draws = words[3]; counters->shaded = words[4];
     }
     return RT_OK;
 }
@@ -339,8 +343,8 @@ int rt_probe_max_depth(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     const bool dev = is_device_pointer(flags_out);
     if (dev) a.rgb = flags_out;
     else { rc = grow(ctx, &ctx->d_stage_rgb, &ctx->stage_rgb_bytes, npix); if (rc) return rc; a.rgb = (unsigned char*)ctx->d_stage_rgb; }
-    LaunchTraits t = { false, true, true, true, false };
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long) + sizeof(int) * 2, ctx->stream));
+    LaunchTraits t = { false, true, true, true, false, true };
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_DEV_WORDS_BYTES, ctx->stream));
     HIP_TRY(ctx, rt_launch_probe(a, t, ctx->stream));
     if (!dev) HIP_TRY(ctx, hipMemcpyAsync(flags_out, a.rgb, npix, hipMemcpyDeviceToHost, ctx->stream));
     int fault = 0;

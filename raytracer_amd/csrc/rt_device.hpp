@@ -46,7 +46,7 @@ struct SceneLds {
     int n_hit, n_lights;
 };
 
-struct Counters { unsigned int closest, shadow, tests, draws; };
+struct Counters { unsigned int closest, shadow, tests, draws, shaded; };
 
 // ---------------------------------------------------------------------------------------------------------------
 // RNG: glibc srand()/rand() TYPE_3 additive-feedback generator (rand.h:7,9), one generator per
@@ -243,39 +243,44 @@ __device__ __forceinline__ bool any_hit(const SceneLds& sc, v3 ro, v3 rd, float 
 
 // LightsList::GetLightIntensity (lightsList.h:22-40) over DirectionalLight (directionalLight.h:11-20) and the
 // repo-defined point light.  The reference asks IsInLight first and the Lambert term second; the result only
-// changes when the Lambert term exceeds the running maximum, so unless COUNT (tallies like the reference) the
-// occlusion query is skipped whenever it cannot matter.  Same value either way.
-template <bool HAS_NONSPHERE, bool COUNT>
+// changes when the Lambert term exceeds the running maximum, so with PRUNE the occlusion query is skipped whenever
+// it cannot matter (same value either way).  Without PRUNE every query the reference issues is issued and tallied,
+// the point light's as the full closest-hit query the reference-side class makes.
+template <bool HAS_NONSPHERE, bool COUNT, bool PRUNE>
 __device__ __forceinline__ float light_intensity(const SceneLds& sc, v3 position, v3 normal, Counters& cnt)
 {
     float intensity = 0.085f;
     for (int i = 0; i < sc.n_lights; ++i) {
         float4 L = sc.lights[i];
         int type = __builtin_amdgcn_readfirstlane(__float_as_int(L.w));
+        v3 l; float dist = 0.0f;
         if (type == L_DIR) {
-            v3 l = mk(L.x, L.y, L.z);
-            float d = dot(normal, l);
-            float intens = d > 0 ? d : 0;
-            if (COUNT) {
-                ++cnt.shadow;
-                if (any_hit<HAS_NONSPHERE, COUNT, false>(sc, position, l, 0.0f, cnt)) continue;
-                if (intens > intensity) intensity = intens;
-            } else if (intens > intensity) {
-                if (!any_hit<HAS_NONSPHERE, COUNT, false>(sc, position, l, 0.0f, cnt)) intensity = intens;
-            }
+            l = mk(L.x, L.y, L.z);
         } else {
             v3 dv = mk(L.x, L.y, L.z) - position;
-            float dist = sqrtf(dot(dv, dv));
-            v3 l = normalize(dv);
-            float d = dot(normal, l);
-            float intens = d > 0 ? d : 0;
-            if (COUNT) {
-                ++cnt.shadow;
-                if (any_hit<HAS_NONSPHERE, COUNT, true>(sc, position, l, dist, cnt)) continue;
-                if (intens > intensity) intensity = intens;
-            } else if (intens > intensity) {
-                if (!any_hit<HAS_NONSPHERE, COUNT, true>(sc, position, l, dist, cnt)) intensity = intens;
+            dist = sqrtf(dot(dv, dv));
+            l = normalize(dv);
+        }
+        float d = dot(normal, l);
+        float intens = d > 0 ? d : 0;
+        if (PRUNE) {
+            if (intens > intensity) {
+                if (COUNT) ++cnt.shadow;
+                bool occluded = (type == L_DIR) ? any_hit<HAS_NONSPHERE, COUNT, false>(sc, position, l, 0.0f, cnt)
+                                                : any_hit<HAS_NONSPHERE, COUNT, true>(sc, position, l, dist, cnt);
+                if (!occluded) intensity = intens;
             }
+        } else {
+            if (COUNT) ++cnt.shadow;
+            bool occluded;
+            if (type == L_DIR) {
+                occluded = any_hit<HAS_NONSPHERE, COUNT, false>(sc, position, l, 0.0f, cnt);
+            } else {
+                float best;
+                int bi = closest_hit<HAS_NONSPHERE, COUNT>(sc, position, l, best, cnt);
+                occluded = bi >= 0 && best < dist;
+            }
+            if (!occluded && intens > intensity) intensity = intens;
         }
     }
     return intensity;

@@ -22,7 +22,7 @@ enum { TAG_REFL = 0, TAG_REFR = 1 };
 //   they are re-read instead of stored.  Mixed parents also keep (emission, strength) in stk_em and, while their
 //   reflection subtree runs, what the refraction step needs (hit position, normal, incoming direction, multiplier,
 //   depth) in `pend`.
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, int MAXSP, int MAXPEND>
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
 __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng<BLOCK>& rng, v3 ro, v3 rd, int maxTotalDepth,
                                               Counters& cnt, int* fault)
 {
@@ -61,7 +61,8 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng<BLOCK>& rn
             } else {
                 Hit h = hit_record(sc, bi, ro, rd, dist);
                 v3 offPosition = h.position + h.normal * 0.005f;                 // renderer.h:55
-                float intensity = light_intensity<HAS_NONSPHERE, COUNT>(sc, offPosition, h.normal, cnt);
+                if (COUNT) ++cnt.shaded;
+                float intensity = light_intensity<HAS_NONSPHERE, COUNT, PRUNE>(sc, offPosition, h.normal, cnt);
                 mat = h.material;
                 const float* m = sc.mats + 10 * mat;
                 color = (mk(m[0], m[1], m[2]) * intensity) * mult;               // renderer.h:64
@@ -191,10 +192,11 @@ __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counte
     atomicAdd(&a.counters[1], (unsigned long long)cnt.shadow);
     atomicAdd(&a.counters[2], (unsigned long long)cnt.tests);
     atomicAdd(&a.counters[3], (unsigned long long)cnt.draws);
+    atomicAdd(&a.counters[4], (unsigned long long)cnt.shaded);
 }
 
 // The per-pixel driver (main.cpp:298-319 == main.cu:38-67) over AntiAliasing (renderer.h:138-201).
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, int MAXSP, int MAXPEND>
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
 __global__ __launch_bounds__(BLOCK) void render_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(KernelArgs a)
 
     Rng<BLOCK> rng;
     rng.init(rng_base, tid, a.seed_base + (unsigned int)(x + y * a.width)); // rand.h:7, main.cpp:304
-    Counters cnt = { 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0 };
 
     v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0);
     float acc_st = 0.0f;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(KernelArgs a)
             float uu = (k & 1) ? u + offX : u - offX;
             float vv = (k & 2) ? v + offY : v - offY;
             v3 dir = uv_to_direction(cam, uu, vv);
-            PathOut p = trace_path<EMISSION, MIXED, HAS_NONSPHERE, COUNT, MAXSP, MAXPEND>(sc, rng, origin, dir, a.max_depth, cnt, a.fault);
+            PathOut p = trace_path<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND>(sc, rng, origin, dir, a.max_depth, cnt, a.fault);
             float md = (float)p.maxDepth;
             res_color = res_color + mk(p.color.x / md, p.color.y / md, p.color.z / md);
             if (EMISSION) {
@@ -289,9 +291,9 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(KernelArgs a)
     const float v = -(((float)y / (float)a.height) * 2.0f - 1.0f);
     Rng<BLOCK> rng;
     rng.init(rng_base, tid, a.seed_base + (unsigned int)(x + y * a.width));
-    Counters cnt = { 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0 };
     v3 dir = uv_to_direction(cam, u, v);
-    PathOut p = trace_path<false, MIXED, HAS_NONSPHERE, false, MAXSP, MAXPEND>(
+    PathOut p = trace_path<false, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND>(
         sc, rng, mk(cam.pos[0], cam.pos[1], cam.pos[2]), dir, a.max_depth, cnt, a.fault);
     a.rgb[(size_t)x + (size_t)y * a.width] = p.maxDepth >= a.max_depth;
 }
@@ -363,10 +365,10 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 // ---- launchers ------------------------------------------------------------------------------------------------
 using namespace rt;
 
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, int MAXSP, int MAXPEND>
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
 static hipError_t launch_one(const KernelArgs& a, int tiles, size_t lds_bytes, hipStream_t stream)
 {
-    auto k = render_kernel<EMISSION, MIXED, HAS_NONSPHERE, COUNT, MAXSP, MAXPEND>;
+    auto k = render_kernel<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND>;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -378,8 +380,8 @@ static hipError_t launch_one(const KernelArgs& a, int tiles, size_t lds_bytes, h
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE>
 static hipError_t launch_depth(const KernelArgs& a, bool deep, int tiles, size_t lds, hipStream_t s)
 {
-    if (deep) return launch_one<EMISSION, MIXED, HAS_NONSPHERE, false, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, s);
-    return launch_one<EMISSION, MIXED, HAS_NONSPHERE, false, RT_STACK_SHALLOW, RT_PEND_SHALLOW>(a, tiles, lds, s);
+    if (deep) return launch_one<EMISSION, MIXED, HAS_NONSPHERE, false, true, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, s);
+    return launch_one<EMISSION, MIXED, HAS_NONSPHERE, false, true, RT_STACK_SHALLOW, RT_PEND_SHALLOW>(a, tiles, lds, s);
 }
 
 size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat)
@@ -393,8 +395,9 @@ hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStrea
     const int tiles = a.tiles_x * a.tiles_y;
     if (tiles <= 0) return hipSuccess;
     const size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
-    if (t.count)   // the tally build is the most general one: emission, mixed, all primitive types, deep stack
-        return launch_one<true, true, true, true, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, stream);
+    // the tally builds are the most general ones: emission, mixed, all primitive types, deep stack
+    if (t.count && !t.prune) return launch_one<true, true, true, true, false, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, stream);
+    if (t.count) return launch_one<true, true, true, true, true, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, stream);
 #define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N) return launch_depth<E, M, N>(a, t.deep, tiles, lds, stream);
     RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
     RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)

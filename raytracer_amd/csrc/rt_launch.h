@@ -25,7 +25,7 @@ struct KernelArgs {
     const float* mats;           // 10 * n_mat
     unsigned char* rgb;          // rows * width * 3 (probe: width * height flags)
     float4* emission;            // rows * width, or null
-    unsigned long long* counters;// 4 words (closest, shadow, tests, draws), or null
+    unsigned long long* counters;// 5 words (closest, shadow, tests, draws, shaded), or null
     int* fault;                  // set to 1 by a kernel whose bounce stack would overflow
 };
 
@@ -34,7 +34,8 @@ struct LaunchTraits {
     bool mixed;      // some material has reflection > 0 and refraction > 0
     bool nonsphere;  // scene holds planes or cubes
     bool deep;       // max_depth needs the deep stack
-    bool count;      // tally like the reference
+    bool count;      // tally queries
+    bool prune;      // with count: tally the production kernel's pruned shadow queries instead of the reference's
 };
 
 size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat);

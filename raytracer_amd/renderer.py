@@ -78,17 +78,17 @@ class Renderer:
         rows = height - row0 if rows is None else rows
         return _abi.Params(width, height, samples, max_depth, seed_base, row0, rows, band_rows, band_stride, flags)
 
-    def render_rows(self, cam, params, rgb_out=None, emission_out=None, count=False):
+    def render_rows(self, cam, params, rgb_out=None, emission_out=None, count=False, executed=False):
         """rt_render_rows into caller buffers (numpy = host, torch cuda tensor = device).  -> counters dict or None"""
         cnt = _abi.Counters()
         if count:
             params = _abi.Params.from_buffer_copy(params)
-            params.flags |= _abi.RT_FLAG_COUNT_LIKE_REFERENCE
+            params.flags |= _abi.RT_FLAG_COUNT_EXECUTED if executed else _abi.RT_FLAG_COUNT_LIKE_REFERENCE
         rc = self._lib.rt_render_rows(self._h, ctypes.byref(cam), ctypes.byref(params), _ptr(rgb_out), _ptr(emission_out),
                                       ctypes.byref(cnt) if count else None)
         self._check(rc, "rt_render_rows")
         if count:
-            return {k: int(getattr(cnt, k)) for k in ("primary", "closest", "shadow", "tests", "rand_draws")}
+            return {k: int(getattr(cnt, k)) for k in ("primary", "closest", "shadow", "tests", "rand_draws", "shaded")}
         return None
 
     def render(self, width, height, samples, max_depth, seed_base=0, emission=False, count=False, cam=None, **rows):

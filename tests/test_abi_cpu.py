@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_abi.Camera35f) == 35 * 4
     assert ctypes.sizeof(_abi.Params) == 48 and _abi.Params.seed_base.offset == 16
-    assert ctypes.sizeof(_abi.Counters) == 40
+    assert ctypes.sizeof(_abi.Counters) == 48
     assert ctypes.sizeof(_abi.SceneSoA) == 88
 
 

@@ -93,7 +93,7 @@ def test_matches_oracle_on_seeded_inputs(rt, name, W, H, samples, depth, seed):
     report(name, rgb, want_rgb)
     assert np.array_equal(rgb, want_rgb)
     assert np.array_equal(em.view(np.uint32), want_em.view(np.uint32))
-    assert cnt == want_cnt
+    assert {k: cnt[k] for k in want_cnt} == want_cnt
     rgb2, _, _ = rt.render(W, H, samples, depth, seed)
     assert np.array_equal(rgb2, want_rgb)
 
@@ -104,7 +104,25 @@ def test_many_objects_small(rt):
     want_rgb, want_em, want_cnt = oracle_lib.render(sc, W, H, samples, depth, seed, threads=8)
     rt.upload_scene(sc)
     rgb, em, cnt = rt.render(W, H, samples, depth, seed, emission=True, count=True)
-    assert np.array_equal(rgb, want_rgb) and np.array_equal(em.view(np.uint32), want_em.view(np.uint32)) and cnt == want_cnt
+    assert np.array_equal(rgb, want_rgb) and np.array_equal(em.view(np.uint32), want_em.view(np.uint32)) and {k: cnt[k] for k in want_cnt} == want_cnt
+
+
+def test_executed_tally_prunes_only_shadow_queries(rt):
+    """RT_FLAG_COUNT_EXECUTED tallies the production kernel: same image, same closest-hit / draw counts, fewer (or
+    equal) shadow queries and primitive tests than the reference issues."""
+    sc = scenes.point_light_scene()
+    W, H, samples, depth, seed = 96, 64, 2, 6, 5
+    rt.upload_scene(sc)
+    cam = ra.camera35f(sc, W, H)
+    p = rt.params(W, H, samples, depth, seed)
+    a = np.zeros((H, W, 3), np.uint8); b = np.zeros((H, W, 3), np.uint8)
+    ref = rt.render_rows(cam, p, a, count=True)
+    exe = rt.render_rows(cam, p, b, count=True, executed=True)
+    assert np.array_equal(a, b)
+    for k in ("primary", "closest", "rand_draws", "shaded"):
+        assert ref[k] == exe[k], k
+    assert exe["shadow"] < ref["shadow"] and exe["tests"] < ref["tests"]
+    assert ref["shadow"] == ref["shaded"] * len(sc.lights)
 
 
 def test_rows_and_cyclic_bands_are_partition_independent(rt):
