@@ -132,7 +132,7 @@ int main(int argc, char** argv)
     const char* scene_path = nullptr; const char* out_ppm = nullptr; const char* out_em = nullptr;
     const char* out_cam = nullptr; const char* out_probe = nullptr;
     int W = 256, H = 128, samples = 5, maxdepth = 10, threads = 0, probe = 0, reps = 1;
-    int row0 = 0, rows = -1;
+    int row0 = 0, rows = -1, row_step = 1;
     for (int i = 1; i < argc; ++i) {
         auto is = [&](const char* k) { return !strcmp(argv[i], k) && i + 1 < argc; };
         if      (is("--scene"))     scene_path = argv[++i];
@@ -149,11 +149,12 @@ int main(int argc, char** argv)
         else if (is("--reps"))      reps = atoi(argv[++i]);
         else if (is("--row0"))      row0 = atoi(argv[++i]);
         else if (is("--rows"))      rows = atoi(argv[++i]);
+        else if (is("--row-step"))  row_step = atoi(argv[++i]);   // sampled rows y = row0 + i*row_step (timing samples)
         else if (!strcmp(argv[i], "--probe")) probe = 1;
         else { fprintf(stderr, "unknown arg %s\n", argv[i]); return 2; }
     }
     if (!scene_path) { fprintf(stderr, "usage: ref_oracle --scene S [--w --h --samples --depth --seed-base --out --emission --threads]\n"); return 2; }
-    if (rows < 0) rows = H - row0;
+    if (rows < 0) rows = (H - row0 + row_step - 1) / row_step;
 
     st_scene sc;
     if (!st_load(scene_path, &sc)) return 2;
@@ -216,10 +217,12 @@ int main(int argc, char** argv)
     if (threads <= 0) {
         auto t0 = std::chrono::steady_clock::now();
         for (int rep = 0; rep < reps; ++rep)
-            for (int y = row0; y < row0 + rows; ++y)
-                for (int x = 0; x < W; ++x)
+            for (int i = 0; i < rows; ++i)
+                for (int x = 0; x < W; ++x) {
+                    int y = row0 + i * row_step;
                     render_pixel(x, y, W, H, samples, maxdepth, &camera, &world, &lights, materials,
                                  &image[x + (size_t)y * W], &emission[x + (size_t)y * W]);
+                }
         ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
     } else {
         g_count = false;
@@ -235,8 +238,9 @@ int main(int argc, char** argv)
                         pool.enqueue([&, sX, sY]() {
                             for (int nY = 0; nY < tile; ++nY)
                                 for (int nX = 0; nX < tile; ++nX) {
-                                    int x = nX + sX * tile, y = row0 + nY + sY * tile;
-                                    if (x >= W || y >= row0 + rows) continue;
+                                    int x = nX + sX * tile, i = nY + sY * tile;
+                                    if (x >= W || i >= rows) continue;
+                                    int y = row0 + i * row_step;
                                     render_pixel(x, y, W, H, samples, maxdepth, &camera, &world, &lights, materials,
                                                  &image[x + (size_t)y * W], &emission[x + (size_t)y * W]);
                                 }

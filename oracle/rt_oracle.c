@@ -515,7 +515,7 @@ static void render_pixel(ctx* c, int x, int y, int W, int H, int samples, long s
 /* ------------------------------------------------------------------ driver: 16x16 tiles on a small pthread pool */
 typedef struct {
     const prepared* p;
-    int W, H, samples, row0, rows; long seed_base;
+    int W, H, samples, row0, rows, row_step; long seed_base;
     unsigned char* rgb; float* emission;
     atomic_int next_tile; int tiles_x, tiles_y;
     ro_counters total; pthread_mutex_t lock;
@@ -533,7 +533,7 @@ static void* worker(void* arg)
             for (int nX = 0; nX < 16; ++nX) {
                 int x = nX + sX * 16, yl = nY + sY * 16;
                 if (x >= j->W || yl >= j->rows) continue;
-                int y = j->row0 + yl;
+                int y = j->row0 + yl * j->row_step;
                 size_t o = (size_t)x + (size_t)yl * j->W;
                 render_pixel(&c, x, y, j->W, j->H, j->samples, j->seed_base,
                              j->rgb ? j->rgb + o * 3 : NULL, j->emission ? j->emission + o * 4 : NULL);
@@ -550,7 +550,15 @@ int ro_render(const ro_scene* scene, const ro_camera* cam, int W, int H, int sam
               long seed_base, int row0, int rows, int threads,
               unsigned char* rgb, float* emission, ro_counters* counters)
 {
-    if (!scene || !cam || W <= 0 || H <= 0 || samples <= 0 || row0 < 0 || rows < 0 || row0 + rows > H) return -1;
+    return ro_render_strided(scene, cam, W, H, samples, maxdepth, seed_base, row0, rows, 1, threads, rgb, emission, counters);
+}
+
+int ro_render_strided(const ro_scene* scene, const ro_camera* cam, int W, int H, int samples, int maxdepth,
+                      long seed_base, int row0, int rows, int row_step, int threads,
+                      unsigned char* rgb, float* emission, ro_counters* counters)
+{
+    if (!scene || !cam || W <= 0 || H <= 0 || samples <= 0 || row0 < 0 || rows < 0 || row_step < 1) return -1;
+    if (rows > 0 && row0 + (rows - 1) * row_step >= H) return -1;
     for (int i = 0; i < scene->n_hittables; ++i) {
         int m = scene->hittables[i].material;
         if (scene->hittables[i].type != RO_CUBE) m = (unsigned char)m;
@@ -558,7 +566,7 @@ int ro_render(const ro_scene* scene, const ro_camera* cam, int W, int H, int sam
     }
     prepared p; prepare(&p, scene, cam, maxdepth);
     job j; memset(&j, 0, sizeof j);
-    j.p = &p; j.W = W; j.H = H; j.samples = samples; j.row0 = row0; j.rows = rows; j.seed_base = seed_base;
+    j.p = &p; j.W = W; j.H = H; j.samples = samples; j.row0 = row0; j.rows = rows; j.row_step = row_step; j.seed_base = seed_base;
     j.rgb = rgb; j.emission = emission;
     j.tiles_x = (W + 15) / 16; j.tiles_y = (rows + 15) / 16;
     atomic_init(&j.next_tile, 0);

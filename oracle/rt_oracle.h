@@ -47,6 +47,11 @@ int ro_render(const ro_scene* scene, const ro_camera* cam, int W, int H, int sam
               long seed_base, int row0, int rows, int threads,
               unsigned char* rgb, float* emission, ro_counters* counters);
 
+/* Same, for the sampled rows y = row0 + i*row_step, i < rows (packed output); used to time a bounded sample. */
+int ro_render_strided(const ro_scene* scene, const ro_camera* cam, int W, int H, int samples, int maxdepth,
+                      long seed_base, int row0, int rows, int row_step, int threads,
+                      unsigned char* rgb, float* emission, ro_counters* counters);
+
 /* tests/singlePixel.cpp:82 -> renderer.h:204-219: flags[x + y*W] = (maxDepth >= maxdepth) for one centre ray. */
 int ro_probe_max_depth(const ro_scene* scene, const ro_camera* cam, int W, int H, int maxdepth,
                        long seed_base, unsigned char* flags);

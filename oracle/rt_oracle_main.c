@@ -15,7 +15,7 @@ int main(int argc, char** argv)
 {
     const char* scene_path = NULL; const char* out_ppm = NULL; const char* out_em = NULL;
     const char* out_cam = NULL; const char* out_probe = NULL;
-    int W = 256, H = 128, samples = 5, maxdepth = 10, threads = 0, probe = 0, reps = 1, row0 = 0, rows = -1;
+    int W = 256, H = 128, samples = 5, maxdepth = 10, threads = 0, probe = 0, reps = 1, row0 = 0, rows = -1, row_step = 1;
     long seed_base = 0;
     for (int i = 1; i < argc; ++i) {
 #define IS(k) (!strcmp(argv[i], k) && i + 1 < argc)
@@ -33,11 +33,12 @@ int main(int argc, char** argv)
         else if (IS("--reps"))      reps = atoi(argv[++i]);
         else if (IS("--row0"))      row0 = atoi(argv[++i]);
         else if (IS("--rows"))      rows = atoi(argv[++i]);
+        else if (IS("--row-step"))  row_step = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--probe")) probe = 1;
         else { fprintf(stderr, "unknown arg %s\n", argv[i]); return 2; }
     }
     if (!scene_path) { fprintf(stderr, "usage: rt_oracle --scene S [--w --h --samples --depth --seed-base --out --emission --threads]\n"); return 2; }
-    if (rows < 0) rows = H - row0;
+    if (rows < 0) rows = (H - row0 + row_step - 1) / row_step;
 
     st_scene sc;
     if (!st_load(scene_path, &sc)) return 2;
@@ -63,8 +64,8 @@ int main(int argc, char** argv)
     ro_counters cnt;
     double t0 = now_ms();
     for (int r = 0; r < reps; ++r)
-        if (ro_render(&scene, &cam, W, H, samples, maxdepth, seed_base, row0, rows, threads,
-                      rgb + (size_t)row0 * W * 3, em + (size_t)row0 * W * 4, &cnt)) { fprintf(stderr, "ro_render failed\n"); return 2; }
+        if (ro_render_strided(&scene, &cam, W, H, samples, maxdepth, seed_base, row0, rows, row_step, threads,
+                              row_step == 1 ? rgb + (size_t)row0 * W * 3 : rgb, row_step == 1 ? em + (size_t)row0 * W * 4 : em, &cnt)) { fprintf(stderr, "ro_render failed\n"); return 2; }
     double ms = (now_ms() - t0) / reps;
 
     if (out_ppm) {

@@ -50,26 +50,24 @@ struct Counters { unsigned int closest, shadow, tests, draws, shaded; };
 
 // ---------------------------------------------------------------------------------------------------------------
 // RNG: glibc srand()/rand() TYPE_3 additive-feedback generator (rand.h:7,9), one generator per
-// pixel.  State = 31 words in LDS, slot-major (word k of thread t at [k*BLOCK + t]) so a wave's access to one slot
-// hits 64 consecutive banks.  Seeding runs in registers (31 words, fully unrolled) and is lazy: most pixels of a
-// diffuse scene never draw.
-template <int BLOCK>
+// pixel: r[f] += r[b]; output r[f] >> 1; f, b step through 31 words, b three behind f.
+// The 31 words live per lane in scratch (a private array indexed at run time); draws come three at a time
+// (RANDOM_UNIT_VECTOR, core.h:24-25) and the three updates touch six distinct words, so their loads are issued
+// together.  Seeding (30 Lehmer steps + 310 discarded outputs) runs in registers, fully unrolled, and is lazy: most
+// pixels of a diffuse scene never draw.
 struct Rng {
-    unsigned int* st;   // LDS base + thread index
-    int f, b;           // front / rear slot (glibc fptr / rptr)
+    unsigned int r[31];
+    int f;              // front slot; rear slot = f - 3 (mod 31)
     bool seeded;
     unsigned int seed;
 
-    __device__ __forceinline__ void init(unsigned int* lds_base, int tid, unsigned int s)
-    {
-        st = lds_base + tid; seed = s; seeded = false; f = 3; b = 0;
-    }
+    __device__ __forceinline__ void init(unsigned int s) { seed = s; seeded = false; f = 3; }
 
     __device__ void do_seed()
     {
-        unsigned int r[31];
+        unsigned int t[31];
         unsigned int s = seed == 0u ? 1u : seed;
-        r[0] = s;
+        t[0] = s;
         int word = (int)s;
 #pragma unroll
         for (int i = 1; i < 31; ++i) {
@@ -78,32 +76,45 @@ struct Rng {
             int lo = word % 127773;
             word = 16807 * lo - 2836 * hi;
             if (word < 0) word += 2147483647;
-            r[i] = (unsigned int)word;
+            t[i] = (unsigned int)word;
         }
-        // discard 310 outputs: 10 full turns of r[(k+3)%31] += r[k]
+        // discard 310 outputs: 10 full turns of t[(k+3)%31] += t[k]
 #pragma unroll 1
         for (int turn = 0; turn < 10; ++turn) {
 #pragma unroll
-            for (int k = 0; k < 31; ++k) r[(k + 3) % 31] += r[k];
+            for (int k = 0; k < 31; ++k) t[(k + 3) % 31] += t[k];
         }
 #pragma unroll
-        for (int k = 0; k < 31; ++k) st[k * BLOCK] = r[k];
-        f = 3; b = 0; seeded = true;
+        for (int k = 0; k < 31; ++k) r[k] = t[k];
+        f = 3; seeded = true;
     }
 
-    // one rand(): r[f] += r[b]; result = r[f] >> 1
+    __device__ __forceinline__ static int wrap(int i) { return i >= 31 ? i - 31 : i; }
+
+    // one rand()
     __device__ __forceinline__ int next()
     {
-        unsigned int v = st[f * BLOCK] + st[b * BLOCK];
-        st[f * BLOCK] = v;
-        f = (f == 30) ? 0 : f + 1;
-        b = (b == 30) ? 0 : b + 1;
+        int b = wrap(f + 28);
+        unsigned int v = r[f] + r[b];
+        r[f] = v;
+        f = wrap(f + 1);
         return (int)(v >> 1);
     }
 
-    // randomUnit() = (float)rand() / (float)RAND_MAX, (float)RAND_MAX == 2^31 (rand.h:9)
-    __device__ __forceinline__ float unit() { return (float)next() * 4.656612873077392578125e-10f; }
+    // three consecutive rand(): words f, f+1, f+2 are updated from words f-3, f-2, f-1 -- no overlap
+    __device__ __forceinline__ void next3(int& o0, int& o1, int& o2)
+    {
+        int f0 = f, f1 = wrap(f + 1), f2 = wrap(f + 2);
+        int b0 = wrap(f + 28), b1 = wrap(f + 29), b2 = wrap(f + 30);
+        unsigned int v0 = r[f0] + r[b0], v1 = r[f1] + r[b1], v2 = r[f2] + r[b2];
+        r[f0] = v0; r[f1] = v1; r[f2] = v2;
+        f = wrap(f + 3);
+        o0 = (int)(v0 >> 1); o1 = (int)(v1 >> 1); o2 = (int)(v2 >> 1);
+    }
 };
+
+// randomUnit() = (float)rand() / (float)RAND_MAX, (float)RAND_MAX == 2^31 (rand.h:9)
+__device__ __forceinline__ float rand_unit(int r) { return (float)r * 4.656612873077392578125e-10f; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Primitive tests.  Each returns whether the reference's intersect() would return true and, if so, hit.distance.
@@ -125,6 +136,27 @@ __device__ __forceinline__ bool sphere_hit(float4 r0, v3 ro, v3 rd, float fa, fl
     if (t2 > t1) dist = (t1 >= 0) ? t1 : t2;
     else         dist = (t2 >= 0) ? t2 : t1;
     return true;
+}
+
+// The boolean of sphere.h:53-73 / :13-33 only (any-hit queries), without the square root where the outcome is already
+// decided.  With sqrtd = RN(sqrt(disc)) >= 0, t2 = (-b + sqrtd)/2 >= t1, so intersect() is true iff !(t2 < 0):
+//   b <= 0            : -b + sqrtd >= 0                                           -> true
+//   b > 0, disc clearly below b*b : sqrtd < b, -b + sqrtd < 0 (and not so tiny that /2 rounds to -0)  -> false
+//   anything else (disc within 1e-4 of b*b, b denormal-small, NaNs)              -> the full test
+__device__ __forceinline__ bool sphere_occludes(float4 r0, v3 ro, v3 rd, float fa)
+{
+    v3 origin = ro - mk(r0.x, r0.y, r0.z);
+    float b = 2.0f * dot(origin, rd);
+    float c = dot(origin, origin) - r0.w;
+    float bb = b * b;
+    float discriminant = bb - fa * c;
+    if (discriminant < 0.0f) return false;
+    if (b <= 0.0f) return true;
+    if (b > 1e-18f && discriminant < bb * 0.9999f) return false;
+    float sqrtd = sqrtf(discriminant);
+    float t1 = (-b - sqrtd) / 2.0f;
+    float t2 = (-b + sqrtd) / 2.0f;
+    return !(t1 < 0 && t2 < 0);
 }
 
 // plane.h:13-23.  The reference compares |denom| against the double 1e-6; for a float x, (double)x <= 1e-6 is
@@ -232,8 +264,14 @@ __device__ __forceinline__ bool any_hit(const SceneLds& sc, v3 ro, v3 rd, float 
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     for (int i = 0; i < sc.n_hit; ++i) {
         float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
-        float d;
         if (COUNT) ++cnt.tests;
+        if (!LIMITED) {
+            // directional light: only the boolean matters
+            bool is_sphere = true;
+            if (HAS_NONSPHERE) is_sphere = __builtin_amdgcn_readfirstlane(rec_type(r1)) == T_SPHERE;
+            if (is_sphere) { if (sphere_occludes(r0, ro, rd, fa)) return true; continue; }
+        }
+        float d;
         if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, d)) {
             if (!LIMITED || d < limit) return true;
         }
@@ -287,15 +325,14 @@ __device__ __forceinline__ float light_intensity(const SceneLds& sc, v3 position
 }
 
 // RANDOM_UNIT_EMISPHERE (core.h:24-35): three draws in x, y, z order, normalise, flip into the normal's hemisphere
-template <int BLOCK, bool COUNT>
-__device__ __forceinline__ v3 random_unit_hemisphere(Rng<BLOCK>& rng, v3 normal, Counters& cnt)
+template <bool COUNT>
+__device__ __forceinline__ v3 random_unit_hemisphere(Rng& rng, v3 normal, Counters& cnt)
 {
     if (!rng.seeded) rng.do_seed();
-    float x = rng.unit();
-    float y = rng.unit();
-    float z = rng.unit();
+    int i0, i1, i2;
+    rng.next3(i0, i1, i2);
     if (COUNT) cnt.draws += 3;
-    v3 rnd = normalize(mk(x, y, z));
+    v3 rnd = normalize(mk(rand_unit(i0), rand_unit(i1), rand_unit(i2)));
     if (dot(rnd, normal) > 0) return rnd;
     return -rnd;
 }

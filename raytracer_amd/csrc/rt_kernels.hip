@@ -23,7 +23,7 @@ enum { TAG_REFL = 0, TAG_REFR = 1 };
 //   reflection subtree runs, what the refraction step needs (hit position, normal, incoming direction, multiplier,
 //   depth) in `pend`.
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
-__device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng<BLOCK>& rng, v3 ro, v3 rd, int maxTotalDepth,
+__device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 ro, v3 rd, int maxTotalDepth,
                                               Counters& cnt, int* fault)
 {
     float4 stk[MAXSP];
@@ -74,7 +74,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng<BLOCK>& rn
                     bool spawned = false;
                     if (reflection > 0) {                                        // renderer.h:74-91
                         v3 d = reflect(rd, hnorm);
-                        v3 hemi = random_unit_hemisphere<BLOCK, COUNT>(rng, hnorm, cnt);
+                        v3 hemi = random_unit_hemisphere<COUNT>(rng, hnorm, cnt);
                         d = normalize(d + hemi * m[3]);
                         if (dot(d, hnorm) > 0) {
                             if (sp >= MAXSP || (MIXED && pp >= MAXPEND)) { *fault = 1; break; }
@@ -115,7 +115,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng<BLOCK>& rn
                     else                        { outNorm = hnorm;  ir = 1.0f / refraction; }
                     v3 d;
                     if (!refract_dir(rayDir, outNorm, ir, d)) d = reflect(rayDir, hnorm);
-                    v3 hemi = random_unit_hemisphere<BLOCK, COUNT>(rng, hnorm, cnt);
+                    v3 hemi = random_unit_hemisphere<COUNT>(rng, hnorm, cnt);
                     d = normalize(d + hemi * m[3]);
                     if (sp >= MAXSP) { *fault = 1; sp = 0; break; }
                     bool mixed = MIXED && reflection > 0;
@@ -169,7 +169,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng<BLOCK>& rn
     return o;
 }
 
-__device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, SceneLds& sc, unsigned int*& rng_base)
+__device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, SceneLds& sc, float*& lds_free)
 {
     const int nrec = 2 * a.n_hit;
     float4* l_hrec = lds;
@@ -179,8 +179,8 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     for (int i = threadIdx.x; i < nrec; i += BLOCK) l_hrec[i] = a.hrec[i];
     for (int i = threadIdx.x; i < a.n_lights; i += BLOCK) l_lights[i] = a.lights[i];
     for (int i = threadIdx.x; i < nm; i += BLOCK) l_mats[i] = a.mats[i];
-    // RNG words start on the next 16-byte boundary
-    rng_base = (unsigned int*)(l_mats + ((nm + 3) & ~3));
+    // per-thread words start on the next 16-byte boundary
+    lds_free = l_mats + ((nm + 3) & ~3);
     sc.hrec = l_hrec; sc.lights = l_lights; sc.mats = l_mats;
     sc.n_hit = a.n_hit; sc.n_lights = a.n_lights;
     __syncthreads();
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
     SceneLds sc;
-    unsigned int* rng_base;
-    stage_scene(a, lds, sc, rng_base);
+    float* lds_free;
+    stage_scene(a, lds, sc, lds_free);
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -223,9 +223,20 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(KernelArgs a)
     const float offX = 0.5f / a.width, offY = 0.5f / a.height;              // main.cpp:306-307
     const v3 origin = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
 
-    Rng<BLOCK> rng;
-    rng.init(rng_base, tid, a.seed_base + (unsigned int)(x + y * a.width)); // rand.h:7, main.cpp:304
+    Rng rng;
+    rng.init(a.seed_base + (unsigned int)(x + y * a.width));                // rand.h:7, main.cpp:304
     Counters cnt = { 0, 0, 0, 0, 0 };
+
+    // AntiAliasing is called with the same (u, v) for every sample (main.cpp:312), so the four primary directions
+    // are per-pixel constants: computed once, parked in LDS (12 words per thread, slot-major: word j of thread t at [j*BLOCK + t]).
+    float* dirs = lds_free + tid;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        float uu = (k & 1) ? u + offX : u - offX;
+        float vv = (k & 2) ? v + offY : v - offY;
+        v3 d = uv_to_direction(cam, uu, vv);
+        dirs[(3 * k + 0) * BLOCK] = d.x; dirs[(3 * k + 1) * BLOCK] = d.y; dirs[(3 * k + 2) * BLOCK] = d.z;
+    }
 
     v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0);
     float acc_st = 0.0f;
@@ -234,12 +245,12 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(KernelArgs a)
         float res_st = 0.0f;
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {                                        // renderer.h:167-195
-            float uu = (k & 1) ? u + offX : u - offX;
-            float vv = (k & 2) ? v + offY : v - offY;
-            v3 dir = uv_to_direction(cam, uu, vv);
+            v3 dir = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
             PathOut p = trace_path<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND>(sc, rng, origin, dir, a.max_depth, cnt, a.fault);
-            float md = (float)p.maxDepth;
-            res_color = res_color + mk(p.color.x / md, p.color.y / md, p.color.z / md);
+            // renderer.h:169: color / vec3(maxDepth); x / 1.0f == x, and most paths end at depth 1
+            v3 pc = p.color;
+            if (p.maxDepth != 1) { float md = (float)p.maxDepth; pc = mk(pc.x / md, pc.y / md, pc.z / md); }
+            res_color = res_color + pc;
             if (EMISSION) {
                 res_em = res_em + p.emission;
                 res_st = (k == 0) ? p.strength : gmax(res_st, p.strength);
@@ -272,8 +283,8 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
     SceneLds sc;
-    unsigned int* rng_base;
-    stage_scene(a, lds, sc, rng_base);
+    float* lds_free;
+    stage_scene(a, lds, sc, lds_free);
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -289,8 +300,8 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(KernelArgs a)
     for (int i = 0; i < 16; ++i) { cam.ip[i] = a.cam[3 + i]; cam.iv[i] = a.cam[19 + i]; }
     const float u = ((float)x / (float)a.width) * 2.0f - 1.0f;
     const float v = -(((float)y / (float)a.height) * 2.0f - 1.0f);
-    Rng<BLOCK> rng;
-    rng.init(rng_base, tid, a.seed_base + (unsigned int)(x + y * a.width));
+    Rng rng;
+    rng.init(a.seed_base + (unsigned int)(x + y * a.width));
     Counters cnt = { 0, 0, 0, 0, 0 };
     v3 dir = uv_to_direction(cam, u, v);
     PathOut p = trace_path<false, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND>(
@@ -323,13 +334,19 @@ __global__ void deinterleave_kernel(const unsigned char* __restrict__ gathered, 
 // ---- unit-test kernels (rt_debug_*) -------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void debug_rand_kernel(const unsigned int* seeds, int n_seeds, int n_draws, int* out)
 {
-    __shared__ unsigned int st[31 * BLOCK];
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_seeds) return;
-    Rng<BLOCK> rng;
-    rng.init(st, threadIdx.x, seeds[i]);
+    Rng rng;
+    rng.init(seeds[i]);
     rng.do_seed();
-    for (int k = 0; k < n_draws; ++k) out[(size_t)i * n_draws + k] = rng.next();
+    // mix the one-at-a-time and the three-at-a-time forms
+    int k = 0;
+    for (; k + 4 <= n_draws; k += 4) {
+        int* o = out + (size_t)i * n_draws + k;
+        o[0] = rng.next();
+        rng.next3(o[1], o[2], o[3]);
+    }
+    for (; k < n_draws; ++k) out[(size_t)i * n_draws + k] = rng.next();
 }
 
 __global__ void debug_quantise_kernel(const float* in, int n, unsigned char* out)
@@ -387,7 +404,7 @@ static hipError_t launch_depth(const KernelArgs& a, bool deep, int tiles, size_t
 size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat)
 {
     size_t nm = (size_t)((10 * n_mat + 3) & ~3);
-    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)31 * BLOCK * 4;
+    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)12 * BLOCK * 4;
 }
 
 hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
