@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="default4_4k_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="extra rt_params.flags for A/B runs (4 = RT_FLAG_NO_TILE_ORDER)")
     args = ap.parse_args()
 
     import numpy as np
@@ -122,7 +123,7 @@ def main():
     rt.upload_scene(scene)
     cam = ra.camera35f(scene, W, H)
     rpr = bands.rows_per_rank(H, BAND_ROWS, world)
-    p = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank)
+    p = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank, flags=args.flags)
     block = torch.zeros((rpr, W, 3), dtype=torch.uint8, device=dev)
 
     def step():
@@ -137,11 +138,12 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    kernel_ms = []
+    kernel_ms, device_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame = step()
         kernel_ms.append(rt.last_kernel_ms)
+        device_ms.append(rt.last_device_ms)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -180,7 +182,7 @@ def main():
                        "seed_base": seed, "parallelism": "cyclic %d-row bands over %d GPU(s), RCCL gather to rank 0" % (BAND_ROWS, world)},
             "rays": {"primary": tot["primary"], "secondary": tot["closest"] - tot["primary"], "shadow_executed": tot["shadow"],
                      "primitive_tests_executed": tot["tests"], "rng_draws": tot["rand_draws"]},
-            "kernel_ms": round(kms, 3),
+            "kernel_ms": round(kms, 3), "device_ms_rank0": round(float(np.mean(device_ms)), 3),
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
                          "note": "algorithmic FP32 flops (SURVEY 8d table x executed tallies) / kernel time from HIP events; "

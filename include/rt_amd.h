@@ -93,6 +93,7 @@ typedef struct {
 } rt_params;
 
 #define RT_FLAG_COUNT_LIKE_REFERENCE 1  /* tally, issuing every shadow query the reference would issue (slower)  */
+#define RT_FLAG_NO_TILE_ORDER         4  /* launch tiles in raster order (skip the cost pre-pass)        */
 #define RT_FLAG_COUNT_EXECUTED       2  /* tally the production kernel's own work (shadow queries that cannot
                                            change the pixel are skipped)                          */
 
@@ -134,8 +135,10 @@ int rt_probe_max_depth(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* pa
 int rt_deinterleave_bands(rt_ctx* ctx, const void* gathered, void* frame_out, int32_t width, int32_t height,
                           int32_t bytes_per_pixel, int32_t band_rows, int32_t nranks, int32_t rows_per_rank);
 
-/* Duration in milliseconds of the last rt_render_rows kernel, from HIP events on the context's stream. */
+/* Durations in milliseconds of the last rt_render_rows, from HIP events on the context's stream: the render kernel
+ * alone, and all device work of the call (cost pre-pass + tile sort + render kernel). */
 float rt_last_kernel_ms(const rt_ctx* ctx);
+float rt_last_device_ms(const rt_ctx* ctx);
 /* hipError_t of the last failing HIP call (0 if none). */
 int rt_last_hip_error(const rt_ctx* ctx);
 const char* rt_strerror(int status);

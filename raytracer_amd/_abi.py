@@ -4,17 +4,19 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+# RT_AMD_LIB lets an A/B experiment point at another build of the same C-ABI
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
 RT_OK = 0
 RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_SCENE = -1, -2, -3, -4
 RT_ERR_UNSUPPORTED, RT_ERR_NO_SCENE, RT_ERR_DEVICE_FAULT = -5, -6, -7
 RT_FLAG_COUNT_LIKE_REFERENCE = 1
 RT_FLAG_COUNT_EXECUTED = 2
+RT_FLAG_NO_TILE_ORDER = 4
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_probe_max_depth",
-    "rt_deinterleave_bands", "rt_last_kernel_ms", "rt_last_hip_error", "rt_strerror",
+    "rt_deinterleave_bands", "rt_last_kernel_ms", "rt_last_device_ms", "rt_last_hip_error", "rt_strerror",
     "rt_debug_rand", "rt_debug_quantise", "rt_debug_intersect",
 ]
 
@@ -74,6 +76,8 @@ def load():
     lib.rt_deinterleave_bands.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32]
     lib.rt_last_kernel_ms.argtypes = [vp]
     lib.rt_last_kernel_ms.restype = ctypes.c_float
+    lib.rt_last_device_ms.argtypes = [vp]
+    lib.rt_last_device_ms.restype = ctypes.c_float
     lib.rt_last_hip_error.argtypes = [vp]
     lib.rt_strerror.argtypes = [ctypes.c_int]
     lib.rt_strerror.restype = ctypes.c_char_p

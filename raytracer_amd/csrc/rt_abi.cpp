@@ -13,8 +13,8 @@
 struct rt_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float last_ms = 0.0f;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;
+    float last_ms = 0.0f, last_total_ms = 0.0f;
     int last_hip = 0;
 
     // uploaded scene
@@ -32,6 +32,9 @@ struct rt_ctx {
     // staging for host-pointer outputs (grown on demand)
     void* d_stage_rgb = nullptr; size_t stage_rgb_bytes = 0;
     void* d_stage_em = nullptr;  size_t stage_em_bytes = 0;
+
+    // tile order: per-tile cost (u32) followed by the launch order (i32)
+    void* d_order = nullptr; size_t order_bytes = 0;
 };
 
 // device words: 5 tallies (u64) followed by the fault flag
@@ -101,12 +104,14 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
 {
     std::memcpy(a.cam, cam, sizeof(float) * 35);
     a.width = p->width; a.height = p->height; a.samples = p->samples; a.max_depth = p->max_depth;
+    a.rays_per_sample = 4;
     a.seed_base = (unsigned int)(uint64_t)p->seed_base;
     a.row0 = p->row0; a.rows = p->rows; a.band_rows = p->band_rows; a.band_stride = p->band_stride;
     a.tiles_x = (p->width + 15) / 16; a.tiles_y = (p->rows + 15) / 16;
     a.n_hit = ctx->n_hit; a.n_lights = ctx->n_lights; a.n_mat = ctx->n_mat;
     a.hrec = ctx->d_hrec; a.lights = ctx->d_lights; a.mats = ctx->d_mats;
     a.rgb = nullptr; a.emission = nullptr; a.counters = ctx->d_counters; a.fault = ctx->d_fault;
+    a.order = nullptr; a.tile_cost = nullptr;
 }
 
 }  // namespace
@@ -147,6 +152,7 @@ int rt_create(rt_ctx** out, int device_ordinal)
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->evm);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, RT_DEV_WORDS_BYTES);
     if (e != hipSuccess) { rt_destroy(ctx); return RT_ERR_HIP; }
     ctx->d_fault = (int*)(ctx->d_counters + 5);
@@ -165,12 +171,15 @@ void rt_destroy(rt_ctx* ctx)
     if (ctx->d_stage_em) (void)hipFree(ctx->d_stage_em);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->evm) (void)hipEventDestroy(ctx->evm);
+    if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 int rt_last_hip_error(const rt_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
 float rt_last_kernel_ms(const rt_ctx* ctx) { return ctx ? ctx->last_ms : 0.0f; }
+float rt_last_device_ms(const rt_ctx* ctx) { return ctx ? ctx->last_total_ms : 0.0f; }
 
 int rt_camera_init(rt_camera35f* cam, float fov_deg, float width, float height, float z_near, float z_far)
 {
@@ -278,7 +287,7 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     if (count && !counters) return RT_ERR_INVALID_ARG;
     if (!rgb_out && !emission_out && !count) return RT_ERR_INVALID_ARG;
     if (counters) std::memset(counters, 0, sizeof(*counters));
-    if (p->rows == 0) { ctx->last_ms = 0.0f; return RT_OK; }
+    if (p->rows == 0) { ctx->last_ms = 0.0f; ctx->last_total_ms = 0.0f; return RT_OK; }
 
     DeviceGuard g(ctx->device);
     if (!g.ok) return RT_ERR_NO_DEVICE;
@@ -302,12 +311,32 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     t.mixed = ctx->mixed;
     t.nonsphere = ctx->nonsphere;
     t.count = count;
+    t.cost = false;
     t.prune = (p->flags & RT_FLAG_COUNT_LIKE_REFERENCE) == 0;
     // frames on the bounce stack <= reflection parents (max_depth) + refraction parents (66)
     t.deep = refraction_chain_bound() + p->max_depth > RT_STACK_SHALLOW || p->max_depth > RT_PEND_SHALLOW - 1;
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_DEV_WORDS_BYTES, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    // Tile order: a 1-sample pre-pass measures every tile's primitive-test count, a counting sort turns
+    // it into a launch order with the expensive tiles first, so the long glass / mirror tiles do not form the tail.
+    // The pre-pass traces one primary ray per pixel (1 / (4 * samples) of the frame's rays) with the tallying build
+    // of the kernel; worth it only on frames with many tiles and several samples.
+    const int tiles = a.tiles_x * a.tiles_y;
+    if (!count && !(p->flags & RT_FLAG_NO_TILE_ORDER) && tiles >= 4096 && p->samples >= 8) {
+        rc = grow(ctx, &ctx->d_order, &ctx->order_bytes, (size_t)tiles * 8);
+        if (rc) return rc;
+        KernelArgs c = a;
+        c.samples = 1; c.rays_per_sample = 1; c.rgb = nullptr; c.emission = nullptr;
+        c.tile_cost = (unsigned int*)ctx->d_order;
+        LaunchTraits tc = t;
+        tc.emission = false; tc.count = true; tc.cost = true; tc.prune = true;
+        HIP_TRY(ctx, rt_launch_render(c, tc, ctx->stream));
+        int* order = (int*)ctx->d_order + tiles;
+        HIP_TRY(ctx, rt_launch_order(c.tile_cost, tiles, order, ctx->stream));
+        a.order = order;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
     HIP_TRY(ctx, rt_launch_render(a, t, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 
@@ -316,7 +345,8 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     unsigned long long words[6] = { 0, 0, 0, 0, 0, 0 };
     HIP_TRY(ctx, hipMemcpyAsync(words, ctx->d_counters, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->ev0, ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->evm, ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_total_ms, ctx->ev0, ctx->ev1));
 
     int fault; std::memcpy(&fault, &words[5], sizeof(int));
     if (fault) return RT_ERR_DEVICE_FAULT;
@@ -343,7 +373,7 @@ int rt_probe_max_depth(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     const bool dev = is_device_pointer(flags_out);
     if (dev) a.rgb = flags_out;
     else { rc = grow(ctx, &ctx->d_stage_rgb, &ctx->stage_rgb_bytes, npix); if (rc) return rc; a.rgb = (unsigned char*)ctx->d_stage_rgb; }
-    LaunchTraits t = { false, true, true, true, false, true };
+    LaunchTraits t = { false, true, true, true, false, false, true };
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_DEV_WORDS_BYTES, ctx->stream));
     HIP_TRY(ctx, rt_launch_probe(a, t, ctx->stream));
     if (!dev) HIP_TRY(ctx, hipMemcpyAsync(flags_out, a.rgb, npix, hipMemcpyDeviceToHost, ctx->stream));

@@ -39,11 +39,22 @@ __device__ __forceinline__ float clamp01(float x) { return gmin(gmax(x, 0.0f), 1
 enum { T_SPHERE = 0, T_PLANE = 1, T_CUBE = 2 };
 enum { L_DIR = 0, L_POINT = 1 };
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(4)))* kptr4;    // constant address space: uniform loads become s_load
+
 struct SceneLds {
     const float4* hrec;   // 2 * n_hit
     const float4* lights; // n_lights
     const float*  mats;   // 10 * n_mat
     int n_hit, n_lights;
+    kptr4 khrec, klights; // the same records in global memory, for wave-uniform (scalar) reads
+#ifdef RT_SCALAR_SCENE
+    __device__ __forceinline__ float4 urec(int i) const { f32x4 v = khrec[i]; return make_float4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ float4 ulight(int i) const { f32x4 v = klights[i]; return make_float4(v.x, v.y, v.z, v.w); }
+#else
+    __device__ __forceinline__ float4 urec(int i) const { return hrec[i]; }
+    __device__ __forceinline__ float4 ulight(int i) const { return lights[i]; }
+#endif
 };
 
 struct Counters { unsigned int closest, shadow, tests, draws, shaded; };
@@ -138,11 +149,14 @@ __device__ __forceinline__ bool sphere_hit(float4 r0, v3 ro, v3 rd, float fa, fl
     return true;
 }
 
-// The boolean of sphere.h:53-73 / :13-33 only (any-hit queries), without the square root where the outcome is already
-// decided.  With sqrtd = RN(sqrt(disc)) >= 0, t2 = (-b + sqrtd)/2 >= t1, so intersect() is true iff !(t2 < 0):
-//   b <= 0            : -b + sqrtd >= 0                                           -> true
-//   b > 0, disc clearly below b*b : sqrtd < b, -b + sqrtd < 0 (and not so tiny that /2 rounds to -0)  -> false
-//   anything else (disc within 1e-4 of b*b, b denormal-small, NaNs)              -> the full test
+// The boolean of sphere.h:13-33 only (any-hit queries), without the square root where the outcome is already decided.
+// With sqrtd = RN(sqrt(disc)) >= 0 and t2 = (-b + sqrtd)/2 >= t1, intersect() is true iff !(t2 < 0):
+//   b <= 0 : -b + sqrtd >= 0                                                                    -> true
+//   b > 0 and disc < bb*(1 - 1e-6), bb = RN(b*b): RN(sqrt(x)) is monotone and RN(sqrt(RN(b*b))) == b, and a disc
+//            that far below bb has sqrt(disc) < b*(1 - 2^-22) < b - ulp(b)/2, so sqrtd < b strictly; -b + sqrtd is
+//            then a negative number of magnitude > b*2^-23, far from the denormals where /2 could round to -0
+//            (b > 1e-18 is required for that)                                                   -> false
+//   anything else (disc within 1e-6 of bb, tiny b, NaNs)                                        -> the full test
 __device__ __forceinline__ bool sphere_occludes(float4 r0, v3 ro, v3 rd, float fa)
 {
     v3 origin = ro - mk(r0.x, r0.y, r0.z);
@@ -152,7 +166,7 @@ __device__ __forceinline__ bool sphere_occludes(float4 r0, v3 ro, v3 rd, float f
     float discriminant = bb - fa * c;
     if (discriminant < 0.0f) return false;
     if (b <= 0.0f) return true;
-    if (b > 1e-18f && discriminant < bb * 0.9999f) return false;
+    if (b > 1e-18f && discriminant < bb * 0.999999f) return false;
     float sqrtd = sqrtf(discriminant);
     float t1 = (-b - sqrtd) / 2.0f;
     float t2 = (-b + sqrtd) / 2.0f;
@@ -246,7 +260,7 @@ __device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, flo
     best = 3.402823466e+38f;   // FLT_MAX
     int bi = -1;
     for (int i = 0; i < sc.n_hit; ++i) {
-        float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+        float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
         float d;
         if (COUNT) ++cnt.tests;
         if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, d) && !(d >= best)) { best = d; bi = i; }
@@ -263,7 +277,7 @@ __device__ __forceinline__ bool any_hit(const SceneLds& sc, v3 ro, v3 rd, float 
     v3 inv = mk(0, 0, 0);
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     for (int i = 0; i < sc.n_hit; ++i) {
-        float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+        float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
         if (COUNT) ++cnt.tests;
         if (!LIMITED) {
             // directional light: only the boolean matters
@@ -289,7 +303,7 @@ __device__ __forceinline__ float light_intensity(const SceneLds& sc, v3 position
 {
     float intensity = 0.085f;
     for (int i = 0; i < sc.n_lights; ++i) {
-        float4 L = sc.lights[i];
+        float4 L = sc.ulight(i);
         int type = __builtin_amdgcn_readfirstlane(__float_as_int(L.w));
         v3 l; float dist = 0.0f;
         if (type == L_DIR) {

@@ -10,6 +10,10 @@
 namespace rt {
 
 constexpr int BLOCK = 256;
+// waves per SIMD the register allocator must leave room for (72 VGPRs at 7); measured in DESIGN.md "occupancy"
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 7
+#endif
 
 struct PathOut { v3 color, emission; float strength; int maxDepth; };
 
@@ -39,7 +43,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 r
     v3 color = mk(0, 0, 0), emission = mk(0, 0, 0);
     float strength = 0.0f;
     int mat = 0;
-    v3 hpos = mk(0, 0, 0), hnorm = mk(0, 0, 0), rayDir = mk(0, 0, 0);
+    v3 hpos = mk(0, 0, 0), hnorm = mk(0, 0, 0), inDir = mk(0, 0, 0);   // inDir: the ray that hit (un-normalised)
 
     for (;;) {
         bool need_refr = false;
@@ -68,7 +72,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 r
                 color = (mk(m[0], m[1], m[2]) * intensity) * mult;               // renderer.h:64
                 if (EMISSION) { emission = mk(m[6], m[7], m[8]); strength = m[9]; }
                 if (depth <= maxTotalDepth) {                                    // renderer.h:68
-                    rayDir = normalize(rd);
+                    inDir = rd;                                                  // normalised only if refraction runs
                     hpos = h.position; hnorm = h.normal;
                     float reflection = m[4];
                     bool spawned = false;
@@ -85,7 +89,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 r
                                 if (EMISSION) stk_em[sp] = make_float4(emission.x, emission.y, emission.z, strength);
                                 pend[3 * pp + 0] = make_float4(hpos.x, hpos.y, hpos.z, mult);
                                 pend[3 * pp + 1] = make_float4(hnorm.x, hnorm.y, hnorm.z, __int_as_float(depth));
-                                pend[3 * pp + 2] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
+                                pend[3 * pp + 2] = make_float4(inDir.x, inDir.y, inDir.z, 0.0f);
                                 ++pp;
                             }
                             ++sp;
@@ -110,6 +114,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 r
                 const float* m = sc.mats + 10 * mat;
                 float reflection = m[4], refraction = m[5];
                 if (refraction > 0) {                                            // renderer.h:93-126
+                    v3 rayDir = normalize(inDir);                                // renderer.h:72
                     v3 outNorm; float ir;
                     if (dot(rayDir, hnorm) > 0) { outNorm = -hnorm; ir = refraction; }
                     else                        { outNorm = hnorm;  ir = 1.0f / refraction; }
@@ -157,7 +162,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 r
                 float4 p0 = pend[3 * pp + 0], p1 = pend[3 * pp + 1], p2 = pend[3 * pp + 2];
                 hpos = mk(p0.x, p0.y, p0.z); mult = p0.w;
                 hnorm = mk(p1.x, p1.y, p1.z); depth = __float_as_int(p1.w);
-                rayDir = mk(p2.x, p2.y, p2.z);
+                inDir = mk(p2.x, p2.y, p2.z);
                 need_refr = true;
             }
         }
@@ -183,6 +188,7 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     lds_free = l_mats + ((nm + 3) & ~3);
     sc.hrec = l_hrec; sc.lights = l_lights; sc.mats = l_mats;
     sc.n_hit = a.n_hit; sc.n_lights = a.n_lights;
+    sc.khrec = (kptr4)a.hrec; sc.klights = (kptr4)a.lights;
     __syncthreads();
 }
 
@@ -195,23 +201,11 @@ __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counte
     atomicAdd(&a.counters[4], (unsigned long long)cnt.shaded);
 }
 
-// The per-pixel driver (main.cpp:298-319 == main.cu:38-67) over AntiAliasing (renderer.h:138-201).
+// The per-pixel driver (main.cpp:298-319 == main.cu:38-67) over AntiAliasing (renderer.h:138-201), for pixel
+// (x, y) of the frame = column x of packed output row r.
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
-__global__ __launch_bounds__(BLOCK) void render_kernel(KernelArgs a)
+__device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds& sc, float* dirs, int x, int y, int r, Counters& cnt)
 {
-    extern __shared__ float4 lds[];
-    SceneLds sc;
-    float* lds_free;
-    stage_scene(a, lds, sc, lds_free);
-
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-    const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int r = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (x >= a.width || r >= a.rows) return;
-    const int y = a.band_rows > 0 ? a.row0 + (r / a.band_rows) * a.band_stride + (r % a.band_rows) : a.row0 + r;
-
     Camera cam;
 #pragma unroll
     for (int i = 0; i < 3; ++i) cam.pos[i] = a.cam[i];
@@ -225,11 +219,9 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(KernelArgs a)
 
     Rng rng;
     rng.init(a.seed_base + (unsigned int)(x + y * a.width));                // rand.h:7, main.cpp:304
-    Counters cnt = { 0, 0, 0, 0, 0 };
 
     // AntiAliasing is called with the same (u, v) for every sample (main.cpp:312), so the four primary directions
-    // are per-pixel constants: computed once, parked in LDS (12 words per thread, slot-major: word j of thread t at [j*BLOCK + t]).
-    float* dirs = lds_free + tid;
+    // are per-pixel constants: computed once, parked in LDS (12 words per thread, word j of thread t at [j*BLOCK + t]).
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         float uu = (k & 1) ? u + offX : u - offX;
@@ -244,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(KernelArgs a)
         v3 res_color = mk(0, 0, 0), res_em = mk(0, 0, 0);
         float res_st = 0.0f;
 #pragma unroll 1
-        for (int k = 0; k < 4; ++k) {                                        // renderer.h:167-195
+        for (int k = 0; k < a.rays_per_sample; ++k) {                        // renderer.h:167-195 (4; 1 in the cost pre-pass)
             v3 dir = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
             PathOut p = trace_path<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND>(sc, rng, origin, dir, a.max_depth, cnt, a.fault);
             // renderer.h:169: color / vec3(maxDepth); x / 1.0f == x, and most paths end at depth 1
@@ -274,7 +266,70 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(KernelArgs a)
     }
     if (EMISSION && a.emission)                                              // main.cpp:319 -> structs.h:39-43
         a.emission[o] = make_float4(acc_em.x / n, acc_em.y / n, acc_em.z / n, acc_st / n);
-    if (COUNT) flush_counters(a, cnt);
+}
+
+// One workgroup = one 16x16 tile (four 8x8 waves).  a.order (optional) maps launch order to tile index so that
+// expensive tiles start first; a.tile_cost (counting builds only) receives the tile's primitive-test count instead of
+// the global tallies -- that is the cost pre-pass (DESIGN.md "tile order").
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
+__global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void render_kernel(KernelArgs a)
+{
+    extern __shared__ float4 lds[];
+    SceneLds sc;
+    float* lds_free;
+    stage_scene(a, lds, sc, lds_free);
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int tile = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int r = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool active = x < a.width && r < a.rows;
+    const int y = a.band_rows > 0 ? a.row0 + (r / a.band_rows) * a.band_stride + (r % a.band_rows) : a.row0 + r;
+
+    Counters cnt = { 0, 0, 0, 0, 0 };
+    if (active)
+        render_pixel<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND>(a, sc, lds_free + tid, x, y, r, cnt);
+
+    if (COUNT) {
+        if (a.tile_cost) {
+            unsigned int* acc = (unsigned int*)(lds_free + 12 * BLOCK);
+            if (tid == 0) *acc = 0;
+            __syncthreads();
+            if (active) atomicAdd(acc, cnt.tests);
+            __syncthreads();
+            if (tid == 0) a.tile_cost[tile] = *acc;
+        } else if (active) {
+            flush_counters(a, cnt);
+        }
+    }
+}
+
+// Launch order from tile costs: counting sort by a 7-bit log-scale key, most expensive first.  One workgroup.
+__global__ __launch_bounds__(1024) void order_kernel(const unsigned int* __restrict__ cost, int n, int* __restrict__ order)
+{
+    __shared__ unsigned int hist[128];
+    __shared__ unsigned int start[128];
+    const int tid = threadIdx.x;
+    if (tid < 128) hist[tid] = 0;
+    __syncthreads();
+    auto key = [](unsigned int c) -> int {
+        // descending cost -> ascending key: 4 buckets per octave
+        if (c == 0) return 127;
+        int e = 31 - __clz(c);
+        int m = e >= 2 ? (int)((c >> (e - 2)) & 3) : 0;
+        int k = e * 4 + m;                 // 0 .. 127
+        return 127 - (k > 127 ? 127 : k);
+    };
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[key(cost[i])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int s = 0;
+        for (int k = 0; k < 128; ++k) { start[k] = s; s += hist[k]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&start[key(cost[i])], 1u)] = i;
 }
 
 // MaxRayDistance (renderer.h:204-219) per pixel, as tests/singlePixel.cpp:74-83 drives it.
@@ -359,7 +414,7 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0;
+    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr;
     v3 ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     float4 r0 = hrec[2 * index], r1 = hrec[2 * index + 1];
     float fa = 4.0f * dot(rd, rd);
@@ -404,7 +459,7 @@ static hipError_t launch_depth(const KernelArgs& a, bool deep, int tiles, size_t
 size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat)
 {
     size_t nm = (size_t)((10 * n_mat + 3) & ~3);
-    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)12 * BLOCK * 4;
+    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)12 * BLOCK * 4 + 16;
 }
 
 hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
@@ -414,7 +469,11 @@ hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStrea
     const size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
     // the tally builds are the most general ones: emission, mixed, all primitive types, deep stack
     if (t.count && !t.prune) return launch_one<true, true, true, true, false, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, stream);
-    if (t.count) return launch_one<true, true, true, true, true, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, stream);
+    if (t.count && !t.cost) return launch_one<true, true, true, true, true, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, stream);
+    if (t.count) {   // cost pre-pass: tallies primitive tests per tile, no emission bookkeeping
+        if (!t.mixed && !t.nonsphere && !t.deep) return launch_one<false, false, false, true, true, RT_STACK_SHALLOW, RT_PEND_SHALLOW>(a, tiles, lds, stream);
+        return launch_one<false, true, true, true, true, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, stream);
+    }
 #define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N) return launch_depth<E, M, N>(a, t.deep, tiles, lds, stream);
     RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
     RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)
@@ -422,6 +481,12 @@ hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStrea
     RT_DISPATCH(true, true, false)   RT_DISPATCH(true, true, true)
 #undef RT_DISPATCH
     return hipErrorInvalidValue;
+}
+
+hipError_t rt_launch_order(const unsigned int* cost, int n, int* order, hipStream_t stream)
+{
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, cost, n, order);
+    return hipGetLastError();
 }
 
 hipError_t rt_launch_probe(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)

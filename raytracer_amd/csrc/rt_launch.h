@@ -16,6 +16,7 @@
 struct KernelArgs {
     float cam[35];               // position, inverse projection, inverse view (rt_camera35f)
     int width, height, samples, max_depth;
+    int rays_per_sample;         // 4 (renderer.h:167-195); the cost pre-pass traces only the first one
     unsigned int seed_base;      // low 32 bits: srand() takes an unsigned int (rand.h:7)
     int row0, rows, band_rows, band_stride;
     int tiles_x, tiles_y;
@@ -27,6 +28,8 @@ struct KernelArgs {
     float4* emission;            // rows * width, or null
     unsigned long long* counters;// 5 words (closest, shadow, tests, draws, shaded), or null
     int* fault;                  // set to 1 by a kernel whose bounce stack would overflow
+    const int* order;            // launch order -> tile index (tiles_x * tiles_y entries), or null = identity
+    unsigned int* tile_cost;     // counting builds: per-tile primitive-test count instead of the global tallies
 };
 
 struct LaunchTraits {
@@ -35,11 +38,13 @@ struct LaunchTraits {
     bool nonsphere;  // scene holds planes or cubes
     bool deep;       // max_depth needs the deep stack
     bool count;      // tally queries
+    bool cost;       // with count: per-tile cost pre-pass (writes KernelArgs::tile_cost)
     bool prune;      // with count: tally the production kernel's pruned shadow queries instead of the reference's
 };
 
 size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat);
 hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
+hipError_t rt_launch_order(const unsigned int* cost, int n, int* order, hipStream_t stream);
 hipError_t rt_launch_probe(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_deinterleave(const void* gathered, void* frame, int row_bytes, int height, int band_rows,
                                   int nranks, int rows_per_rank, hipStream_t stream);

@@ -116,6 +116,10 @@ class Renderer:
     def last_kernel_ms(self):
         return float(self._lib.rt_last_kernel_ms(self._h))
 
+    @property
+    def last_device_ms(self):
+        return float(self._lib.rt_last_device_ms(self._h))
+
     # unit-test hooks
     def debug_rand(self, seeds, n_draws):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)

@@ -125,6 +125,24 @@ def test_executed_tally_prunes_only_shadow_queries(rt):
     assert ref["shadow"] == ref["shaded"] * len(sc.lights)
 
 
+def test_tile_order_prepass_does_not_change_pixels(rt):
+    """Frames with >= 4096 tiles and >= 8 spp go through the cost pre-pass + expensive-first launch order."""
+    from raytracer_amd import _abi
+    sc = scenes.glass_mirror()
+    W, H, samples, depth, seed = 1024, 1024, 8, 12, 3
+    rt.upload_scene(sc)
+    cam = ra.camera35f(sc, W, H)
+    a = np.zeros((H, W, 3), np.uint8); b = np.zeros((H, W, 3), np.uint8)
+    ea = np.zeros((H, W, 4), np.float32); eb = np.zeros((H, W, 4), np.float32)
+    rt.render_rows(cam, rt.params(W, H, samples, depth, seed), a, ea)
+    t_order = rt.last_device_ms
+    rt.render_rows(cam, rt.params(W, H, samples, depth, seed, flags=_abi.RT_FLAG_NO_TILE_ORDER), b, eb)
+    print("device ms with tile order %.2f, raster order %.2f" % (t_order, rt.last_device_ms))
+    assert np.array_equal(a, b) and np.array_equal(ea.view(np.uint32), eb.view(np.uint32))
+    want, _, _ = oracle_lib.render(sc, W, H, samples, depth, seed, row0=480, rows=64, threads=8, want_emission=False)
+    assert np.array_equal(a[480:544], want)
+
+
 def test_rows_and_cyclic_bands_are_partition_independent(rt):
     sc = scenes.glass_mirror()
     W, H, samples, depth, seed = 120, 100, 2, 6, 9
