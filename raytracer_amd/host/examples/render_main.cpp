@@ -1,0 +1,95 @@
+// Drop-in demonstration: a driver written like the reference's (src/main.cpp:231-411 without Redis / Postgres / glow,
+// src/main.cu:458-572 without CUDA) on top of the API-compatible host headers.  The scene is either the reference's
+// default rows (src/postgres.h:207-210,224-227,191 == src/main.cu:74,83-86,522-525), built with the same `new Sphere`
+// / `new HittablesList` / `new DirectionalLight` / `new LightsList` calls, or an rtscene file.
+//
+//   rt_render [--scene file] [--w 1024 --h 512 --samples 5 --depth 10 --seed-base 0] [--out output.ppm]
+//             [--emission out.f32] [--probe] [--speedup]
+#include "../renderer.h"
+
+#include "../lights/directionalLight.h"
+#include "../lights/lightsList.h"
+#include "../hittables/hittablesList.h"
+#include "../hittables/sphere.h"
+#include "../scene_io.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+int main(int argc, char** argv)
+{
+    RenderSettings st;
+    const char* scenePath = nullptr; const char* out = "output.ppm"; const char* outEm = nullptr;
+    bool probe = false, speedup = false;
+    for (int i = 1; i < argc; ++i) {
+        auto is = [&](const char* k) { return !std::strcmp(argv[i], k) && i + 1 < argc; };
+        if      (is("--scene"))     scenePath = argv[++i];
+        else if (is("--w"))         st.width = std::atoi(argv[++i]);
+        else if (is("--h"))         st.height = std::atoi(argv[++i]);
+        else if (is("--samples"))   st.samples = std::atoi(argv[++i]);
+        else if (is("--depth"))     st.maxDepth = std::atoi(argv[++i]);
+        else if (is("--seed-base")) st.seedBase = std::atoll(argv[++i]);
+        else if (is("--device"))    st.device = std::atoi(argv[++i]);
+        else if (is("--out"))       out = argv[++i];
+        else if (is("--emission"))  outEm = argv[++i];
+        else if (!std::strcmp(argv[i], "--probe"))   probe = true;
+        else if (!std::strcmp(argv[i], "--speedup")) speedup = true;
+        else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+
+    LoadedScene loaded;
+    Material* materials = nullptr; int materialsCount = 0;
+    Hittable* world = nullptr; Light* lights = nullptr;
+    float fov = 60.0f, znear = 0.01f, zfar = 1000.0f;
+    Material defaults[4];
+    std::vector<Hittable*> l_world; std::vector<Light*> l_light;
+    if (scenePath) {
+        if (!LoadScene(scenePath, loaded)) return 2;
+        materials = loaded.materials.data(); materialsCount = (int)loaded.materials.size();
+        world = loaded.world; lights = loaded.lights;
+        fov = loaded.fov; znear = loaded.znear; zfar = loaded.zfar;
+    } else {
+        // -- Init Lights
+        l_light.push_back(new DirectionalLight({ -0.25f, -0.75f, 0.45f }));
+        lights = new LightsList(l_light.data(), (uint32_t)l_light.size());
+        // -- Init Materials
+        defaults[0] = Material{ { 0.8f, 0.8f, 0.0f }, 0.0f,  0.0f,  0.0f,  { 0.0f, 0.0f, 0.0f }, 0.0f };
+        defaults[1] = Material{ { 0.8f, 0.2f, 0.1f }, 0.08f, 0.02f, 0.0f,  { 1.0f, 0.0f, 0.0f }, 4.5f };
+        defaults[2] = Material{ { 0.8f, 0.8f, 0.8f }, 0.9f,  0.75f, 0.0f,  { 0.0f, 0.0f, 0.0f }, 0.0f };
+        defaults[3] = Material{ { 0.0f, 0.0f, 0.0f }, 0.0f,  0.0f,  1.85f, { 0.0f, 0.0f, 0.0f }, 0.0f };
+        materials = defaults; materialsCount = 4;
+        // -- Init world
+        l_world.push_back(new Sphere({  0.0f, -1000.0f, -4.0f }, 1000.0f, 0));
+        l_world.push_back(new Sphere({  0.0f,  1.0f,    -4.0f }, 1.0f,    1));
+        l_world.push_back(new Sphere({ -3.0f,  1.0f,    -4.0f }, 1.0f,    2));
+        l_world.push_back(new Sphere({  3.0f,  1.0f,    -4.0f }, 1.0f,    3));
+        world = new HittablesList(l_world.data(), (uint32_t)l_world.size());
+    }
+
+    Camera camera(fov, (float)st.width, (float)st.height, znear, zfar);
+    int rc = 0;
+    if (probe) {
+        int any = MaxRayDistanceAny(camera, world, lights, materials, materialsCount, st);
+        if (any < 0) { std::fprintf(stderr, "probe failed: %s\n", rt_strerror(any)); rc = 1; }
+        else std::printf("Status: %s!\n", any ? "Failed" : "Success");                     // src/tests/singlePixel.cpp:120
+    } else if (speedup) {
+        double ms = RenderTimed(camera, world, lights, materials, st);
+        if (ms < 0) rc = 1; else std::printf("Ended in: %lf\n", ms);                       // src/tests/speedUp.cpp:48
+    } else {
+        std::vector<pixel> image((size_t)st.width * st.height);
+        std::vector<emissionPixel> emission(outEm ? (size_t)st.width * st.height : 0);
+        double ms = 0.0;
+        std::printf("Running Raytracing on MI355X...\n");
+        int status = RenderImage(camera, world, lights, materials, materialsCount, st, image.data(),
+                                 outEm ? emission.data() : nullptr, &ms);
+        if (status != RT_OK) { std::fprintf(stderr, "RenderImage failed: %s\n", rt_strerror(status)); rc = 1; }
+        else {
+            std::printf("Ended in: %lf ms\n", ms);
+            writePPM(out, image.data(), st.width, st.height);
+            if (outEm) { FILE* f = std::fopen(outEm, "wb"); std::fwrite(emission.data(), sizeof(emissionPixel), emission.size(), f); std::fclose(f); }
+        }
+    }
+    if (!scenePath) { delete lights; delete world; }
+    return rc;
+}
