@@ -24,6 +24,9 @@ struct rt_ctx {
     void* d_scene = nullptr;       // hrec | lights | mats
     size_t scene_bytes = 0;
     const float4* d_hrec = nullptr; const float4* d_lights = nullptr; const float* d_mats = nullptr;
+    float4* d_prim = nullptr;                    // camera-relative sphere terms, refreshed when the camera moves
+    std::vector<float> h_centres_r2;             // host copy of (centre, r^2) per hittable
+    float prim_cam[3] = { 0, 0, 0 }; bool prim_valid = false;
 
     // small device words: 4 counters (u64) + fault flag
     unsigned long long* d_counters = nullptr;
@@ -112,6 +115,28 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
     a.hrec = ctx->d_hrec; a.lights = ctx->d_lights; a.mats = ctx->d_mats;
     a.rgb = nullptr; a.emission = nullptr; a.counters = ctx->d_counters; a.fault = ctx->d_fault;
     a.order = nullptr; a.tile_cost = nullptr;
+    a.prim = ctx->d_prim;
+}
+
+// Primary rays all start at the camera: origin - centre and dot(origin, origin) - r*r (sphere.h:15,19) are per-sphere
+// constants of a frame.  Same float operations, same order, done once here instead of once per ray.
+int refresh_primary_terms(rt_ctx* ctx, const rt_camera35f* cam)
+{
+    if (ctx->nonsphere || ctx->n_hit == 0) return RT_OK;
+    if (ctx->prim_valid && std::memcmp(ctx->prim_cam, cam->position, 12) == 0) return RT_OK;
+    std::vector<float> prim((size_t)ctx->n_hit * 4);
+    const rtm::vec3 eye(cam->position[0], cam->position[1], cam->position[2]);
+    for (int i = 0; i < ctx->n_hit; ++i) {
+        const float* r = &ctx->h_centres_r2[4 * (size_t)i];
+        const rtm::vec3 oc = eye - rtm::vec3(r[0], r[1], r[2]);
+        prim[4 * (size_t)i + 0] = oc.x; prim[4 * (size_t)i + 1] = oc.y; prim[4 * (size_t)i + 2] = oc.z;
+        prim[4 * (size_t)i + 3] = rtm::dot(oc, oc) - r[3];
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_prim, prim.data(), prim.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `prim` is a pageable temporary
+    std::memcpy(ctx->prim_cam, cam->position, 12);
+    ctx->prim_valid = true;
+    return RT_OK;
 }
 
 }  // namespace
@@ -211,7 +236,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     }
 
     const int nh = s->n_hittables, nl = s->n_lights, nm = s->n_materials;
-    std::vector<float> img((size_t)nh * 8 + (size_t)nl * 4 + (size_t)nm * 10 + 4, 0.0f);
+    std::vector<float> img((size_t)nh * 8 + (size_t)nl * 4 + (size_t)nm * 10 + 4 + (size_t)nh * 4, 0.0f);
     float* hrec = img.data();
     float* lights = hrec + (size_t)nh * 8;
     float* mats = lights + (size_t)nl * 4;
@@ -272,6 +297,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     ctx->d_hrec = (const float4*)ctx->d_scene;
     ctx->d_lights = (const float4*)((const float*)ctx->d_scene + (size_t)nh * 8);
     ctx->d_mats = (const float*)ctx->d_scene + (size_t)nh * 8 + (size_t)nl * 4;
+    ctx->d_prim = (float4*)((float*)ctx->d_scene + (size_t)nh * 8 + (size_t)nl * 4 + (((size_t)nm * 10 + 3) & ~(size_t)3));
+    ctx->h_centres_r2.resize((size_t)nh * 4);
+    for (int i = 0; i < nh; ++i) std::memcpy(&ctx->h_centres_r2[4 * (size_t)i], hrec + 8 * (size_t)i, 16);
+    ctx->prim_valid = false;
     ctx->n_hit = nh; ctx->n_lights = nl; ctx->n_mat = nm;
     ctx->mixed = mixed; ctx->nonsphere = nonsphere;
     ctx->has_scene = true;
@@ -292,6 +321,8 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     DeviceGuard g(ctx->device);
     if (!g.ok) return RT_ERR_NO_DEVICE;
 
+    rc = refresh_primary_terms(ctx, cam);
+    if (rc != RT_OK) return rc;
     KernelArgs a;
     fill_args(ctx, cam, p, a);
     const size_t npix = (size_t)p->width * p->rows;
@@ -365,6 +396,8 @@ int rt_probe_max_depth(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     DeviceGuard g(ctx->device);
     if (!g.ok) return RT_ERR_NO_DEVICE;
 
+    rc = refresh_primary_terms(ctx, cam);
+    if (rc != RT_OK) return rc;
     KernelArgs a;
     fill_args(ctx, cam, p, a);
     a.row0 = 0; a.rows = p->height; a.band_rows = 0; a.band_stride = 0;

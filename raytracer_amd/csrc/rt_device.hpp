@@ -48,6 +48,7 @@ struct SceneLds {
     const float*  mats;   // 10 * n_mat
     int n_hit, n_lights;
     kptr4 khrec, klights; // the same records in global memory, for wave-uniform (scalar) reads
+    kptr4 kprim;          // per sphere (camera - centre, |camera - centre|^2 - r^2): primary rays share their origin
 #ifdef RT_SCALAR_SCENE
     __device__ __forceinline__ float4 urec(int i) const { f32x4 v = khrec[i]; return make_float4(v.x, v.y, v.z, v.w); }
     __device__ __forceinline__ float4 ulight(int i) const { f32x4 v = klights[i]; return make_float4(v.x, v.y, v.z, v.w); }
@@ -67,14 +68,14 @@ struct Counters { unsigned int closest, shadow, tests, draws, shaded; };
 // together.  Seeding (30 Lehmer steps + 310 discarded outputs) runs in registers, fully unrolled, and is lazy: most
 // pixels of a diffuse scene never draw.
 struct Rng {
-    unsigned int r[31];
+    unsigned int* r;    // the lane's 31 words (a private array of the caller: keeps f / seeded / seed in registers)
     int f;              // front slot; rear slot = f - 3 (mod 31)
     bool seeded;
     unsigned int seed;
 
-    __device__ __forceinline__ void init(unsigned int s) { seed = s; seeded = false; f = 3; }
+    __device__ __forceinline__ void init(unsigned int* words, unsigned int s) { r = words; seed = s; seeded = false; f = 3; }
 
-    __device__ void do_seed()
+    __device__ __noinline__ void do_seed()
     {
         unsigned int t[31];
         unsigned int s = seed == 0u ? 1u : seed;
@@ -132,12 +133,11 @@ __device__ __forceinline__ float rand_unit(int r) { return (float)r * 4.65661287
 // Position / normal are produced afterwards for the winning hittable only (same values: the reference overwrites
 // them on every accepted candidate, hittablesList.h:27-31).
 
-// sphere.h:13-44.  `a` = dot(dir,dir) and `fa` = 4*a are per-ray values.
-__device__ __forceinline__ bool sphere_hit(float4 r0, v3 ro, v3 rd, float fa, float& dist)
+// sphere.h:13-44.  `a` = dot(dir,dir) and `fa` = 4*a are per-ray values; origin = ray.origin - centre and
+// c = dot(origin, origin) - r*r depend on the ray's origin only.
+__device__ __forceinline__ bool sphere_hit_oc(v3 origin, float c, v3 rd, float fa, float& dist)
 {
-    v3 origin = ro - mk(r0.x, r0.y, r0.z);
     float b = 2.0f * dot(origin, rd);
-    float c = dot(origin, origin) - r0.w;
     float discriminant = b * b - fa * c;
     if (discriminant < 0.0f) return false;
     float sqrtd = sqrtf(discriminant);
@@ -147,6 +147,13 @@ __device__ __forceinline__ bool sphere_hit(float4 r0, v3 ro, v3 rd, float fa, fl
     if (t2 > t1) dist = (t1 >= 0) ? t1 : t2;
     else         dist = (t2 >= 0) ? t2 : t1;
     return true;
+}
+
+__device__ __forceinline__ bool sphere_hit(float4 r0, v3 ro, v3 rd, float fa, float& dist)
+{
+    v3 origin = ro - mk(r0.x, r0.y, r0.z);
+    float c = dot(origin, origin) - r0.w;
+    return sphere_hit_oc(origin, c, rd, fa, dist);
 }
 
 // The boolean of sphere.h:13-33 only (any-hit queries), without the square root where the outcome is already decided.
@@ -264,6 +271,23 @@ __device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, flo
         float d;
         if (COUNT) ++cnt.tests;
         if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, d) && !(d >= best)) { best = d; bi = i; }
+    }
+    return bi;
+}
+
+// The same query for a primary ray of a sphere-only scene: all primary rays start at the camera, so
+// (origin - centre, dot(..) - r*r) come precomputed per sphere (rt_abi.cpp, the same float operations).
+template <bool COUNT>
+__device__ __forceinline__ int closest_hit_primary(const SceneLds& sc, v3 rd, float& best, Counters& cnt)
+{
+    float fa = 4.0f * dot(rd, rd);
+    best = 3.402823466e+38f;
+    int bi = -1;
+    for (int i = 0; i < sc.n_hit; ++i) {
+        f32x4 p = sc.kprim[i];
+        float d;
+        if (COUNT) ++cnt.tests;
+        if (sphere_hit_oc(mk(p.x, p.y, p.z), p.w, rd, fa, d) && !(d >= best)) { best = d; bi = i; }
     }
     return bi;
 }

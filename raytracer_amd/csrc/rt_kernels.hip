@@ -44,6 +44,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 r
     float strength = 0.0f;
     int mat = 0;
     v3 hpos = mk(0, 0, 0), hnorm = mk(0, 0, 0), inDir = mk(0, 0, 0);   // inDir: the ray that hit (un-normalised)
+    bool primary = true;          // wave-uniform: every lane's first query is its primary ray
 
     for (;;) {
         bool need_refr = false;
@@ -55,7 +56,10 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 r
         } else {
             if (COUNT) ++cnt.closest;
             float dist;
-            int bi = closest_hit<HAS_NONSPHERE, COUNT>(sc, ro, rd, dist, cnt);
+            int bi;
+            if (!HAS_NONSPHERE && primary) bi = closest_hit_primary<COUNT>(sc, rd, dist, cnt);
+            else                           bi = closest_hit<HAS_NONSPHERE, COUNT>(sc, ro, rd, dist, cnt);
+            primary = false;
             if (bi < 0) {                                                        // renderer.h:40-50
                 maxDepth = depth;
                 float a = (rd.y + 1.0f) * 0.5f;
@@ -188,7 +192,7 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     lds_free = l_mats + ((nm + 3) & ~3);
     sc.hrec = l_hrec; sc.lights = l_lights; sc.mats = l_mats;
     sc.n_hit = a.n_hit; sc.n_lights = a.n_lights;
-    sc.khrec = (kptr4)a.hrec; sc.klights = (kptr4)a.lights;
+    sc.khrec = (kptr4)a.hrec; sc.klights = (kptr4)a.lights; sc.kprim = (kptr4)a.prim;
     __syncthreads();
 }
 
@@ -217,8 +221,9 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
     const float offX = 0.5f / a.width, offY = 0.5f / a.height;              // main.cpp:306-307
     const v3 origin = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
 
+    unsigned int rng_words[31];
     Rng rng;
-    rng.init(a.seed_base + (unsigned int)(x + y * a.width));                // rand.h:7, main.cpp:304
+    rng.init(rng_words, a.seed_base + (unsigned int)(x + y * a.width));                // rand.h:7, main.cpp:304
 
     // AntiAliasing is called with the same (u, v) for every sample (main.cpp:312), so the four primary directions
     // are per-pixel constants: computed once, parked in LDS (12 words per thread, word j of thread t at [j*BLOCK + t]).
@@ -355,8 +360,9 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(KernelArgs a)
     for (int i = 0; i < 16; ++i) { cam.ip[i] = a.cam[3 + i]; cam.iv[i] = a.cam[19 + i]; }
     const float u = ((float)x / (float)a.width) * 2.0f - 1.0f;
     const float v = -(((float)y / (float)a.height) * 2.0f - 1.0f);
+    unsigned int rng_words[31];
     Rng rng;
-    rng.init(a.seed_base + (unsigned int)(x + y * a.width));
+    rng.init(rng_words, a.seed_base + (unsigned int)(x + y * a.width));
     Counters cnt = { 0, 0, 0, 0, 0 };
     v3 dir = uv_to_direction(cam, u, v);
     PathOut p = trace_path<false, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND>(
@@ -391,8 +397,9 @@ __global__ __launch_bounds__(BLOCK) void debug_rand_kernel(const unsigned int* s
 {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_seeds) return;
+    unsigned int rng_words[31];
     Rng rng;
-    rng.init(seeds[i]);
+    rng.init(rng_words, seeds[i]);
     rng.do_seed();
     // mix the one-at-a-time and the three-at-a-time forms
     int k = 0;
@@ -414,7 +421,7 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr;
+    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr;
     v3 ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     float4 r0 = hrec[2 * index], r1 = hrec[2 * index + 1];
     float fa = 4.0f * dot(rd, rd);
