@@ -12,7 +12,8 @@ RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_SCENE = -1, -2, -3, -4
 RT_ERR_UNSUPPORTED, RT_ERR_NO_SCENE, RT_ERR_DEVICE_FAULT = -5, -6, -7
 RT_FLAG_COUNT_LIKE_REFERENCE = 1
 RT_FLAG_COUNT_EXECUTED = 2
-RT_FLAG_NO_TILE_ORDER = 4
+RT_FLAG_SINGLE_KERNEL = 4
+RT_FLAG_FORCE_SAMPLE_PARALLEL = 8
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_probe_max_depth",

@@ -10,10 +10,20 @@
 #include <new>
 #include <vector>
 
+// sample-parallel pixels: table capacity (8 KiB of generator states per pixel) and the hand-over threshold in
+// draws(sample 0) * (samples - 1); a pixel below it is quicker left to its own lane
+#ifndef RT_HEAVY_CAP
+#define RT_HEAVY_CAP 16384
+#endif
+#ifndef RT_HEAVY_MIN_WORK
+#define RT_HEAVY_MIN_WORK 12000u
+#endif
+
 struct rt_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;
+    hipStream_t stream = nullptr;      // everything but the listed general kernel
+    hipStream_t stream2 = nullptr;     // the listed general kernel, beside the direct kernel
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, ev_list = nullptr, ev_gen = nullptr;
     float last_ms = 0.0f, last_total_ms = 0.0f;
     int last_hip = 0;
 
@@ -36,8 +46,10 @@ struct rt_ctx {
     void* d_stage_rgb = nullptr; size_t stage_rgb_bytes = 0;
     void* d_stage_em = nullptr;  size_t stage_em_bytes = 0;
 
-    // tile order: per-tile cost (u32) followed by the launch order (i32)
-    void* d_order = nullptr; size_t order_bytes = 0;
+    // pixel classes: keys (u16 per pixel) | pixel list (u32 per pixel) | histogram + cursor (2 * RT_MAX_KEYS u32)
+    void* d_classes = nullptr; size_t classes_bytes = 0;
+    void* d_heavy = nullptr; size_t heavy_bytes = 0;   // sample-parallel pixels: count | records | generator states
+    bool any_bounce = false;             // some material has reflection > 0 or refraction > 0
 };
 
 // device words: 5 tallies (u64) followed by the fault flag
@@ -107,14 +119,15 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
 {
     std::memcpy(a.cam, cam, sizeof(float) * 35);
     a.width = p->width; a.height = p->height; a.samples = p->samples; a.max_depth = p->max_depth;
-    a.rays_per_sample = 4;
     a.seed_base = (unsigned int)(uint64_t)p->seed_base;
     a.row0 = p->row0; a.rows = p->rows; a.band_rows = p->band_rows; a.band_stride = p->band_stride;
     a.tiles_x = (p->width + 15) / 16; a.tiles_y = (p->rows + 15) / 16;
     a.n_hit = ctx->n_hit; a.n_lights = ctx->n_lights; a.n_mat = ctx->n_mat;
     a.hrec = ctx->d_hrec; a.lights = ctx->d_lights; a.mats = ctx->d_mats;
     a.rgb = nullptr; a.emission = nullptr; a.counters = ctx->d_counters; a.fault = ctx->d_fault;
-    a.order = nullptr; a.tile_cost = nullptr;
+    a.keys = nullptr; a.hist = nullptr; a.list = nullptr; a.list_count = 0; a.list_count_dev = nullptr;
+    a.fallback_count = nullptr; a.fallback_list = nullptr;
+    a.heavy_count = nullptr; a.heavy_rec = nullptr; a.heavy_state = nullptr; a.heavy_cap = 0; a.heavy_min_work = 0;
     a.prim = ctx->d_prim;
 }
 
@@ -178,6 +191,9 @@ int rt_create(rt_ctx** out, int device_ordinal)
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->evm);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_list, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gen, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, RT_DEV_WORDS_BYTES);
     if (e != hipSuccess) { rt_destroy(ctx); return RT_ERR_HIP; }
     ctx->d_fault = (int*)(ctx->d_counters + 5);
@@ -197,7 +213,11 @@ void rt_destroy(rt_ctx* ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evm) (void)hipEventDestroy(ctx->evm);
-    if (ctx->d_order) (void)hipFree(ctx->d_order);
+    if (ctx->ev_list) (void)hipEventDestroy(ctx->ev_list);
+    if (ctx->ev_gen) (void)hipEventDestroy(ctx->ev_gen);
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->d_classes) (void)hipFree(ctx->d_classes);
+    if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -226,13 +246,14 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     if (s->n_hittables > RT_MAX_HITTABLES || s->n_lights > RT_MAX_LIGHTS || s->n_materials > RT_MAX_MATERIALS)
         return RT_ERR_UNSUPPORTED;
 
-    bool mixed = false;
+    bool mixed = false, any_bounce = false;
     for (int i = 0; i < s->n_materials; ++i) {
         const float reflection = s->materials[10 * i + 4], refraction = s->materials[10 * i + 5];
         // reflection > 1 lets the multiplier grow: the reference's recursion is then bounded by nothing but depth
         // for reflections and by nothing at all through refractions (renderer.h:82,118)
         if (reflection > 1.0f || reflection != reflection || refraction != refraction) return RT_ERR_UNSUPPORTED;
         if (reflection > 0.0f && refraction > 0.0f) mixed = true;
+        if (reflection > 0.0f || refraction > 0.0f) any_bounce = true;
     }
 
     const int nh = s->n_hittables, nl = s->n_lights, nm = s->n_materials;
@@ -302,7 +323,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     for (int i = 0; i < nh; ++i) std::memcpy(&ctx->h_centres_r2[4 * (size_t)i], hrec + 8 * (size_t)i, 16);
     ctx->prim_valid = false;
     ctx->n_hit = nh; ctx->n_lights = nl; ctx->n_mat = nm;
-    ctx->mixed = mixed; ctx->nonsphere = nonsphere;
+    ctx->mixed = mixed; ctx->nonsphere = nonsphere; ctx->any_bounce = any_bounce;
     ctx->has_scene = true;
     return RT_OK;
 }
@@ -342,33 +363,76 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     t.mixed = ctx->mixed;
     t.nonsphere = ctx->nonsphere;
     t.count = count;
-    t.cost = false;
+    t.listed = false;
     t.prune = (p->flags & RT_FLAG_COUNT_LIKE_REFERENCE) == 0;
     // frames on the bounce stack <= reflection parents (max_depth) + refraction parents (66)
     t.deep = refraction_chain_bound() + p->max_depth > RT_STACK_SHALLOW || p->max_depth > RT_PEND_SHALLOW - 1;
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_DEV_WORDS_BYTES, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    // Tile order: a 1-sample pre-pass measures every tile's primitive-test count, a counting sort turns
-    // it into a launch order with the expensive tiles first, so the long glass / mirror tiles do not form the tail.
-    // The pre-pass traces one primary ray per pixel (1 / (4 * samples) of the frame's rays) with the tallying build
-    // of the kernel; worth it only on frames with many tiles and several samples.
-    const int tiles = a.tiles_x * a.tiles_y;
-    if (!count && !(p->flags & RT_FLAG_NO_TILE_ORDER) && tiles >= 4096 && p->samples >= 8) {
-        rc = grow(ctx, &ctx->d_order, &ctx->order_bytes, (size_t)tiles * 8);
-        if (rc) return rc;
-        KernelArgs c = a;
-        c.samples = 1; c.rays_per_sample = 1; c.rgb = nullptr; c.emission = nullptr;
-        c.tile_cost = (unsigned int*)ctx->d_order;
-        LaunchTraits tc = t;
-        tc.emission = false; tc.count = true; tc.cost = true; tc.prune = true;
-        HIP_TRY(ctx, rt_launch_render(c, tc, ctx->stream));
-        int* order = (int*)ctx->d_order + tiles;
-        HIP_TRY(ctx, rt_launch_order(c.tile_cost, tiles, order, ctx->stream));
-        a.order = order;
+    if (count || (p->flags & RT_FLAG_SINGLE_KERNEL)) {
+        // tallying builds and the A/B flag: the general kernel over every pixel
+        HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
+        HIP_TRY(ctx, rt_launch_render(a, t, ctx->stream));
+    } else {
+        // Two kernels side by side (DESIGN.md "execution model").  Pixels whose primary rays can bounce -- found by
+        // one closest-hit query per primary direction -- go, grouped by material, to the general kernel on a second
+        // stream; all other pixels need no RNG, stack or scratch and go to the direct kernel.
+        const bool bounces = ctx->any_bounce && p->max_depth >= 1;       // renderer.h:68: depth 1 <= maxTotalDepth
+        unsigned int n_listed = 0;
+        if (bounces) {
+            const size_t keys_bytes = (npix * 2 + 15) & ~(size_t)15;
+            rc = grow(ctx, &ctx->d_classes, &ctx->classes_bytes, keys_bytes + npix * 4 + 2 * RT_MAX_KEYS * 4);
+            if (rc) return rc;
+            a.keys = (unsigned short*)ctx->d_classes;
+            unsigned int* list = (unsigned int*)((char*)ctx->d_classes + keys_bytes);
+            a.hist = list + npix;
+            unsigned int* cursor = a.hist + RT_MAX_KEYS;
+            HIP_TRY(ctx, hipMemsetAsync(a.hist, 0, 2 * RT_MAX_KEYS * 4, ctx->stream));
+            HIP_TRY(ctx, rt_launch_classify(a, t, cursor, list, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_list, ctx->stream));
+            // the list length sizes the general kernel's grid: scan_kernel leaves it in cursor[0] ... which scatter does
+            // not touch (keys are >= 1), so it can be read as soon as the list is complete
+            HIP_TRY(ctx, hipMemcpyAsync(&n_listed, cursor, sizeof(n_listed), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (n_listed > 0) {
+                KernelArgs g2 = a;
+                g2.list = list; g2.list_count = (int)n_listed;
+                LaunchTraits tg = t;
+                tg.listed = true;
+                // Long pixels leave the listed kernel after their first sample and are finished one wave per pixel,
+                // one lane per sample, by the heavy kernel behind it (DESIGN.md "sample-parallel pixels").
+                const bool force = (p->flags & RT_FLAG_FORCE_SAMPLE_PARALLEL) != 0;
+                if (p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
+                    const size_t cap = n_listed < RT_HEAVY_CAP ? n_listed : RT_HEAVY_CAP;
+                    rc = grow(ctx, &ctx->d_heavy, &ctx->heavy_bytes, 16 + cap * 4 * (64 * 32 + RT_HEAVY_REC_WORDS + 1));
+                    if (rc) return rc;
+                    g2.heavy_count = (unsigned int*)ctx->d_heavy;
+                    g2.fallback_count = g2.heavy_count + 1;
+                    g2.heavy_state = g2.heavy_count + 4;
+                    g2.heavy_rec = g2.heavy_state + cap * (64 * 32);
+                    g2.fallback_list = g2.heavy_rec + cap * RT_HEAVY_REC_WORDS;
+                    g2.heavy_cap = (int)cap;
+                    g2.heavy_min_work = force ? 0u : RT_HEAVY_MIN_WORK;
+                    HIP_TRY(ctx, hipMemsetAsync(g2.heavy_count, 0, 16, ctx->stream2));
+                }
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_list, 0));
+                HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream2));
+                if (g2.heavy_cap > 0) {
+                    HIP_TRY(ctx, rt_launch_heavy(g2, tg, ctx->stream2));
+                    // pixels the heavy kernel gave up on: the listed kernel again, without hand-over
+                    KernelArgs g3 = g2;
+                    g3.list = g2.fallback_list; g3.list_count = g2.heavy_cap; g3.list_count_dev = g2.fallback_count;
+                    g3.heavy_cap = 0;
+                    HIP_TRY(ctx, rt_launch_render(g3, tg, ctx->stream2));
+                }
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_gen, ctx->stream2));
+            }
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
+        if (n_listed < npix) HIP_TRY(ctx, rt_launch_direct(a, t, ctx->stream));
+        if (n_listed > 0) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gen, 0));
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
-    HIP_TRY(ctx, rt_launch_render(a, t, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 
     if (rgb_out && !rgb_dev) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, a.rgb, npix * 3, hipMemcpyDeviceToHost, ctx->stream));

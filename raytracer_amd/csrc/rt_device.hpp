@@ -7,6 +7,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef RT_UNROLL
+#define RT_UNROLL 1
+#endif
+#define RT_INF __builtin_huge_valf()
+
 namespace rt {
 
 struct v3 { float x, y, z; };
@@ -63,19 +68,24 @@ struct Counters { unsigned int closest, shadow, tests, draws, shaded; };
 // ---------------------------------------------------------------------------------------------------------------
 // RNG: glibc srand()/rand() TYPE_3 additive-feedback generator (rand.h:7,9), one generator per
 // pixel: r[f] += r[b]; output r[f] >> 1; f, b step through 31 words, b three behind f.
-// The 31 words live per lane in scratch (a private array indexed at run time); draws come three at a time
-// (RANDOM_UNIT_VECTOR, core.h:24-25) and the three updates touch six distinct words, so their loads are issued
-// together.  Seeding (30 Lehmer steps + 310 discarded outputs) runs in registers, fully unrolled, and is lazy: most
-// pixels of a diffuse scene never draw.
-struct Rng {
-    unsigned int* r;    // the lane's 31 words (a private array of the caller: keeps f / seeded / seed in registers)
+// The 31 words live per lane either in scratch (STRIDE 1: a private array indexed at run time) or in LDS, slot-major
+// (STRIDE = workgroup size: word k of thread t at [k*STRIDE + t], a wave's access to one slot is 64 consecutive
+// banks).  Draws come three at a time (RANDOM_UNIT_VECTOR, core.h:24-25) and the three updates touch six distinct
+// words, so their loads are issued together.  Seeding (30 Lehmer steps + 310 discarded outputs) runs in registers,
+// fully unrolled and out of line, and is lazy: most pixels of a diffuse scene never draw.
+template <int STRIDE>
+struct RngT {
+    static constexpr int stride = STRIDE;
+    unsigned int* r;    // the lane's word 0
     int f;              // front slot; rear slot = f - 3 (mod 31)
     bool seeded;
     unsigned int seed;
+    unsigned int ndraws;   // rand() calls so far
 
-    __device__ __forceinline__ void init(unsigned int* words, unsigned int s) { r = words; seed = s; seeded = false; f = 3; }
+    __device__ __forceinline__ void init(unsigned int* words, unsigned int s) { r = words; seed = s; seeded = false; f = 3; ndraws = 0; }
 
-    __device__ __noinline__ void do_seed()
+    // srand(seed): out of line, so that its 31 live words never share a register budget with the hot loops
+    __device__ __noinline__ static void seed_words(unsigned int* r, unsigned int seed)
     {
         unsigned int t[31];
         unsigned int s = seed == 0u ? 1u : seed;
@@ -97,9 +107,10 @@ struct Rng {
             for (int k = 0; k < 31; ++k) t[(k + 3) % 31] += t[k];
         }
 #pragma unroll
-        for (int k = 0; k < 31; ++k) r[k] = t[k];
-        f = 3; seeded = true;
+        for (int k = 0; k < 31; ++k) r[k * STRIDE] = t[k];
     }
+
+    __device__ __forceinline__ void do_seed() { seed_words(r, seed); f = 3; seeded = true; }
 
     __device__ __forceinline__ static int wrap(int i) { return i >= 31 ? i - 31 : i; }
 
@@ -107,9 +118,10 @@ struct Rng {
     __device__ __forceinline__ int next()
     {
         int b = wrap(f + 28);
-        unsigned int v = r[f] + r[b];
-        r[f] = v;
+        unsigned int v = r[f * STRIDE] + r[b * STRIDE];
+        r[f * STRIDE] = v;
         f = wrap(f + 1);
+        ndraws += 1;
         return (int)(v >> 1);
     }
 
@@ -118,12 +130,15 @@ struct Rng {
     {
         int f0 = f, f1 = wrap(f + 1), f2 = wrap(f + 2);
         int b0 = wrap(f + 28), b1 = wrap(f + 29), b2 = wrap(f + 30);
-        unsigned int v0 = r[f0] + r[b0], v1 = r[f1] + r[b1], v2 = r[f2] + r[b2];
-        r[f0] = v0; r[f1] = v1; r[f2] = v2;
+        unsigned int v0 = r[f0 * STRIDE] + r[b0 * STRIDE], v1 = r[f1 * STRIDE] + r[b1 * STRIDE], v2 = r[f2 * STRIDE] + r[b2 * STRIDE];
+        r[f0 * STRIDE] = v0; r[f1 * STRIDE] = v1; r[f2 * STRIDE] = v2;
         f = wrap(f + 3);
+        ndraws += 3;
         o0 = (int)(v0 >> 1); o1 = (int)(v1 >> 1); o2 = (int)(v2 >> 1);
     }
 };
+
+typedef RngT<1> Rng;   // words in a private (scratch) array
 
 // randomUnit() = (float)rand() / (float)RAND_MAX, (float)RAND_MAX == 2^31 (rand.h:9)
 __device__ __forceinline__ float rand_unit(int r) { return (float)r * 4.656612873077392578125e-10f; }
@@ -258,7 +273,9 @@ __device__ __forceinline__ Hit hit_record(const SceneLds& sc, int idx, v3 ro, v3
 
 // HittablesList::intersect (hittablesList.h:17-37): brute force, strict '<' so the earlier hittable wins ties;
 // a candidate replaces the best unless `dist >= best` (NaN distances therefore replace, as in the reference).
-template <bool HAS_NONSPHERE, bool COUNT>
+// BATCH > 1 reads the records of BATCH hittables before testing the first: one memory round trip per BATCH tests,
+// for kernels whose waves wait on latency rather than on issue slots.
+template <bool HAS_NONSPHERE, bool COUNT, int BATCH = 1>
 __device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, float& best, Counters& cnt)
 {
     float fa = 4.0f * dot(rd, rd);
@@ -266,28 +283,67 @@ __device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, flo
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     best = 3.402823466e+38f;   // FLT_MAX
     int bi = -1;
-    for (int i = 0; i < sc.n_hit; ++i) {
+    int i = 0;
+    if (BATCH > 1) {
+        for (; i + BATCH <= sc.n_hit; i += BATCH) {
+            float4 r[2 * BATCH];
+#pragma unroll
+            for (int j = 0; j < 2 * BATCH; ++j) r[j] = sc.urec(2 * i + j);
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                if (COUNT) ++cnt.tests;
+                float d = RT_INF;
+                float t;
+                if (hittable_hit<HAS_NONSPHERE>(r[2 * j], r[2 * j + 1], ro, rd, fa, inv, t)) d = t;
+                if (!(d >= best)) { best = d; bi = i + j; }
+            }
+        }
+    }
+#pragma unroll RT_UNROLL
+    for (; i < sc.n_hit; ++i) {
         float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
-        float d;
         if (COUNT) ++cnt.tests;
-        if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, d) && !(d >= best)) { best = d; bi = i; }
+        float d = RT_INF;
+        float t;
+        if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, t)) d = t;
+        if (!(d >= best)) { best = d; bi = i; }
     }
     return bi;
 }
 
 // The same query for a primary ray of a sphere-only scene: all primary rays start at the camera, so
 // (origin - centre, dot(..) - r*r) come precomputed per sphere (rt_abi.cpp, the same float operations).
-template <bool COUNT>
+template <bool COUNT, int BATCH = 1>
 __device__ __forceinline__ int closest_hit_primary(const SceneLds& sc, v3 rd, float& best, Counters& cnt)
 {
     float fa = 4.0f * dot(rd, rd);
     best = 3.402823466e+38f;
     int bi = -1;
-    for (int i = 0; i < sc.n_hit; ++i) {
+    int i = 0;
+    if (BATCH > 1) {
+        for (; i + BATCH <= sc.n_hit; i += BATCH) {
+            f32x4 p[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) p[j] = sc.kprim[i + j];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                if (COUNT) ++cnt.tests;
+                float d = RT_INF;
+                float t;
+                if (sphere_hit_oc(mk(p[j].x, p[j].y, p[j].z), p[j].w, rd, fa, t)) d = t;
+                if (!(d >= best)) { best = d; bi = i + j; }
+            }
+        }
+    }
+#pragma unroll RT_UNROLL
+    for (; i < sc.n_hit; ++i) {
         f32x4 p = sc.kprim[i];
-        float d;
         if (COUNT) ++cnt.tests;
-        if (sphere_hit_oc(mk(p.x, p.y, p.z), p.w, rd, fa, d) && !(d >= best)) { best = d; bi = i; }
+        // a miss yields +inf, which `!(d >= best)` rejects exactly like the reference's `continue`
+        float d = RT_INF;
+        float t;
+        if (sphere_hit_oc(mk(p.x, p.y, p.z), p.w, rd, fa, t)) d = t;
+        if (!(d >= best)) { best = d; bi = i; }
     }
     return bi;
 }
@@ -295,24 +351,42 @@ __device__ __forceinline__ int closest_hit_primary(const SceneLds& sc, v3 rd, fl
 // HittablesList::hasIntersect (hittablesList.h:39-50): first hittable whose intersect() is true, no distance bound.
 // With `limit`: the point-light occlusion test "some hittable is hit strictly closer than the light".
 template <bool HAS_NONSPHERE, bool COUNT, bool LIMITED>
+__device__ __forceinline__ bool occluder_hit(float4 r0, float4 r1, v3 ro, v3 rd, float fa, v3 inv, float limit)
+{
+    if (!LIMITED) {
+        // directional light: only the boolean matters
+        bool is_sphere = true;
+        if (HAS_NONSPHERE) is_sphere = __builtin_amdgcn_readfirstlane(rec_type(r1)) == T_SPHERE;
+        if (is_sphere) return sphere_occludes(r0, ro, rd, fa);
+    }
+    float d;
+    if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, d)) return !LIMITED || d < limit;
+    return false;
+}
+
+template <bool HAS_NONSPHERE, bool COUNT, bool LIMITED, int BATCH = 1>
 __device__ __forceinline__ bool any_hit(const SceneLds& sc, v3 ro, v3 rd, float limit, Counters& cnt)
 {
     float fa = 4.0f * dot(rd, rd);
     v3 inv = mk(0, 0, 0);
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-    for (int i = 0; i < sc.n_hit; ++i) {
+    int i = 0;
+    if (BATCH > 1) {
+        for (; i + BATCH <= sc.n_hit; i += BATCH) {
+            float4 r[2 * BATCH];
+#pragma unroll
+            for (int j = 0; j < 2 * BATCH; ++j) r[j] = sc.urec(2 * i + j);
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                if (COUNT) ++cnt.tests;
+                if (occluder_hit<HAS_NONSPHERE, COUNT, LIMITED>(r[2 * j], r[2 * j + 1], ro, rd, fa, inv, limit)) return true;
+            }
+        }
+    }
+    for (; i < sc.n_hit; ++i) {
         float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
         if (COUNT) ++cnt.tests;
-        if (!LIMITED) {
-            // directional light: only the boolean matters
-            bool is_sphere = true;
-            if (HAS_NONSPHERE) is_sphere = __builtin_amdgcn_readfirstlane(rec_type(r1)) == T_SPHERE;
-            if (is_sphere) { if (sphere_occludes(r0, ro, rd, fa)) return true; continue; }
-        }
-        float d;
-        if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, d)) {
-            if (!LIMITED || d < limit) return true;
-        }
+        if (occluder_hit<HAS_NONSPHERE, COUNT, LIMITED>(r0, r1, ro, rd, fa, inv, limit)) return true;
     }
     return false;
 }
@@ -322,7 +396,7 @@ __device__ __forceinline__ bool any_hit(const SceneLds& sc, v3 ro, v3 rd, float 
 // changes when the Lambert term exceeds the running maximum, so with PRUNE the occlusion query is skipped whenever
 // it cannot matter (same value either way).  Without PRUNE every query the reference issues is issued and tallied,
 // the point light's as the full closest-hit query the reference-side class makes.
-template <bool HAS_NONSPHERE, bool COUNT, bool PRUNE>
+template <bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int BATCH = 1>
 __device__ __forceinline__ float light_intensity(const SceneLds& sc, v3 position, v3 normal, Counters& cnt)
 {
     float intensity = 0.085f;
@@ -342,8 +416,8 @@ __device__ __forceinline__ float light_intensity(const SceneLds& sc, v3 position
         if (PRUNE) {
             if (intens > intensity) {
                 if (COUNT) ++cnt.shadow;
-                bool occluded = (type == L_DIR) ? any_hit<HAS_NONSPHERE, COUNT, false>(sc, position, l, 0.0f, cnt)
-                                                : any_hit<HAS_NONSPHERE, COUNT, true>(sc, position, l, dist, cnt);
+                bool occluded = (type == L_DIR) ? any_hit<HAS_NONSPHERE, COUNT, false, BATCH>(sc, position, l, 0.0f, cnt)
+                                                : any_hit<HAS_NONSPHERE, COUNT, true, BATCH>(sc, position, l, dist, cnt);
                 if (!occluded) intensity = intens;
             }
         } else {
@@ -363,8 +437,8 @@ __device__ __forceinline__ float light_intensity(const SceneLds& sc, v3 position
 }
 
 // RANDOM_UNIT_EMISPHERE (core.h:24-35): three draws in x, y, z order, normalise, flip into the normal's hemisphere
-template <bool COUNT>
-__device__ __forceinline__ v3 random_unit_hemisphere(Rng& rng, v3 normal, Counters& cnt)
+template <bool COUNT, class RNG>
+__device__ __forceinline__ v3 random_unit_hemisphere(RNG& rng, v3 normal, Counters& cnt)
 {
     if (!rng.seeded) rng.do_seed();
     int i0, i1, i2;

@@ -1,9 +1,13 @@
 // HIP kernels of the TraceRay hot path for gfx950 and their launchers.  See DESIGN.md for the execution model.
 //
-// One thread owns one pixel (its RNG stream is strictly sequential: rand.h seeds per pixel, main.cpp:304), one wave
-// owns an 8x8 pixel tile, one 256-thread workgroup a 16x16 tile (the reference's CPU tile, main.cpp:275).  The scene
-// is staged once per workgroup into LDS; the recursion of renderer.h:28-135 is an explicit per-lane stack machine
-// whose frames live in scratch, so colour and emission are still combined child-to-parent in the reference's order.
+// One thread owns one pixel (its RNG stream is strictly sequential: rand.h seeds per pixel, main.cpp:304).  A frame
+// is rendered by two kernels that run side by side (DESIGN.md "execution model"):
+//   direct_kernel  -- pixels none of whose four primary rays hits a reflective / refractive material: every ray is
+//                     closest hit + one shading, no RNG, no bounce stack, no scratch; 8x8-pixel waves, 16x16 tiles;
+//   render_kernel  -- the general per-pixel driver (iterative TraceRay with its stack in scratch) over the compacted,
+//                     material-sorted list of the remaining pixels, at raised wave priority.
+// classify_kernel decides which pixel goes where (one closest-hit query per primary direction), scan / scatter kernels
+// build the list.  Tallying builds (tests, bench ray counts) run render_kernel over every pixel instead.
 #include "rt_device.hpp"
 #include "rt_launch.h"
 
@@ -13,6 +17,29 @@ constexpr int BLOCK = 256;
 // waves per SIMD the register allocator must leave room for (72 VGPRs at 7); measured in DESIGN.md "occupancy"
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 7
+#endif
+// the listed render_kernel (DESIGN.md "execution model"): generator words in LDS, scene records fetched in batches
+#ifndef RT_LISTED_LDS_RNG
+#define RT_LISTED_LDS_RNG 1
+#endif
+#ifndef RT_LISTED_BATCH
+#define RT_LISTED_BATCH 4
+#endif
+#ifndef RT_DIRECT_BATCH
+#define RT_DIRECT_BATCH 4
+#endif
+#ifndef RT_LISTED_WAVES
+#define RT_LISTED_WAVES 4
+#endif
+// sample-parallel pixels: at most this many samples (one wave, one lane per sample)
+#define RT_HEAVY_SAMPLES 64
+// re-guesses per pixel before it is sent back to the serial kernel
+// samples the serial kernel does first: they must all draw the same count for the pixel to be handed over
+#ifndef RT_HEAVY_PROBE
+#define RT_HEAVY_PROBE 4
+#endif
+#ifndef RT_HEAVY_ROUNDS
+#define RT_HEAVY_ROUNDS 4
 #endif
 
 struct PathOut { v3 color, emission; float strength; int maxDepth; };
@@ -26,8 +53,8 @@ enum { TAG_REFL = 0, TAG_REFR = 1 };
 //   they are re-read instead of stored.  Mixed parents also keep (emission, strength) in stk_em and, while their
 //   reflection subtree runs, what the refraction step needs (hit position, normal, incoming direction, multiplier,
 //   depth) in `pend`.
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
-__device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 ro, v3 rd, int maxTotalDepth,
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, class RNG = Rng, int BATCH = 1>
+__device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 ro, v3 rd, int maxTotalDepth,
                                               Counters& cnt, int* fault)
 {
     float4 stk[MAXSP];
@@ -58,7 +85,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 r
             float dist;
             int bi;
             if (!HAS_NONSPHERE && primary) bi = closest_hit_primary<COUNT>(sc, rd, dist, cnt);
-            else                           bi = closest_hit<HAS_NONSPHERE, COUNT>(sc, ro, rd, dist, cnt);
+            else                           bi = closest_hit<HAS_NONSPHERE, COUNT, BATCH>(sc, ro, rd, dist, cnt);
             primary = false;
             if (bi < 0) {                                                        // renderer.h:40-50
                 maxDepth = depth;
@@ -70,7 +97,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 r
                 Hit h = hit_record(sc, bi, ro, rd, dist);
                 v3 offPosition = h.position + h.normal * 0.005f;                 // renderer.h:55
                 if (COUNT) ++cnt.shaded;
-                float intensity = light_intensity<HAS_NONSPHERE, COUNT, PRUNE>(sc, offPosition, h.normal, cnt);
+                float intensity = light_intensity<HAS_NONSPHERE, COUNT, PRUNE, BATCH>(sc, offPosition, h.normal, cnt);
                 mat = h.material;
                 const float* m = sc.mats + 10 * mat;
                 color = (mk(m[0], m[1], m[2]) * intensity) * mult;               // renderer.h:64
@@ -141,6 +168,19 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, Rng& rng, v3 r
             }
             // the current node is complete: hand (color, emission, strength) to its parent
             if (sp == 0) break;
+            if (!MIXED && !EMISSION && BATCH > 1) {
+                // every remaining frame only adds its colour (renderer.h:83,119): fetch four frames per round trip,
+                // add them in the same order
+                while (sp >= 4) {
+                    float4 f0 = stk[sp - 1], f1 = stk[sp - 2], f2 = stk[sp - 3], f3 = stk[sp - 4];
+                    sp -= 4;
+                    color = mk(f0.x, f0.y, f0.z) + color;
+                    color = mk(f1.x, f1.y, f1.z) + color;
+                    color = mk(f2.x, f2.y, f2.z) + color;
+                    color = mk(f3.x, f3.y, f3.z) + color;
+                }
+                if (sp == 0) break;
+            }
             --sp;
             float4 fr = stk[sp];
             int meta = __float_as_int(fr.w);
@@ -205,28 +245,51 @@ __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counte
     atomicAdd(&a.counters[4], (unsigned long long)cnt.shaded);
 }
 
-// The per-pixel driver (main.cpp:298-319 == main.cu:38-67) over AntiAliasing (renderer.h:138-201), for pixel
-// (x, y) of the frame = column x of packed output row r.
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
-__device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds& sc, float* dirs, int x, int y, int r, Counters& cnt)
+// Pixel -> frame coordinates.  Tiled: workgroup = 16x16 tile, wave = 8x8 block.  Listed: lane i of the grid takes
+// entry i of the pixel list (index into the packed output, row-major).
+struct PixelId { int x, y, r; bool active; };
+
+__device__ __forceinline__ int frame_row(const KernelArgs& a, int r)
+{
+    return a.band_rows > 0 ? a.row0 + (r / a.band_rows) * a.band_stride + (r % a.band_rows) : a.row0 + r;
+}
+
+__device__ __forceinline__ PixelId tiled_pixel(const KernelArgs& a)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    PixelId p;
+    p.x = tx * 16 + (wave & 1) * 8 + (lane & 7);
+    p.r = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    p.active = p.x < a.width && p.r < a.rows;
+    p.y = frame_row(a, p.r);
+    return p;
+}
+
+__device__ __forceinline__ PixelId listed_pixel(const KernelArgs& a)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    PixelId p;
+    const unsigned int n = a.list_count_dev ? *a.list_count_dev : (unsigned int)a.list_count;
+    p.active = (unsigned int)i < n;
+    const unsigned int o = p.active ? a.list[i] : 0u;
+    p.x = (int)(o % (unsigned int)a.width);
+    p.r = (int)(o / (unsigned int)a.width);
+    p.y = frame_row(a, p.r);
+    return p;
+}
+
+// The four primary directions of a pixel (renderer.h:140,167,175,183,191 over main.cpp:301-307) into LDS words.
+__device__ __forceinline__ void primary_directions(const KernelArgs& a, float* dirs, int x, int y)
 {
     Camera cam;
 #pragma unroll
     for (int i = 0; i < 3; ++i) cam.pos[i] = a.cam[i];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { cam.ip[i] = a.cam[3 + i]; cam.iv[i] = a.cam[19 + i]; }
-
-    const float u = ((float)x / (float)a.width) * 2.0f - 1.0f;              // main.cpp:301-302
-    const float v = -(((float)y / (float)a.height) * 2.0f - 1.0f);          // renderer.h:140
-    const float offX = 0.5f / a.width, offY = 0.5f / a.height;              // main.cpp:306-307
-    const v3 origin = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
-
-    unsigned int rng_words[31];
-    Rng rng;
-    rng.init(rng_words, a.seed_base + (unsigned int)(x + y * a.width));                // rand.h:7, main.cpp:304
-
-    // AntiAliasing is called with the same (u, v) for every sample (main.cpp:312), so the four primary directions
-    // are per-pixel constants: computed once, parked in LDS (12 words per thread, word j of thread t at [j*BLOCK + t]).
+    const float u = ((float)x / (float)a.width) * 2.0f - 1.0f;
+    const float v = -(((float)y / (float)a.height) * 2.0f - 1.0f);
+    const float offX = 0.5f / a.width, offY = 0.5f / a.height;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         float uu = (k & 1) ? u + offX : u - offX;
@@ -234,6 +297,227 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
         v3 d = uv_to_direction(cam, uu, vv);
         dirs[(3 * k + 0) * BLOCK] = d.x; dirs[(3 * k + 1) * BLOCK] = d.y; dirs[(3 * k + 2) * BLOCK] = d.z;
     }
+}
+
+// One AntiAliasing call (renderer.h:138-201) and the clamps the pixel driver applies to its result (main.cpp:313-315).
+// dirs: the pixel's four primary directions, word j at dirs[j * BLOCK].
+struct SampleOut { v3 color, emission; float strength; };
+
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, class RNG, int BATCH>
+__device__ __forceinline__ SampleOut render_sample(const KernelArgs& a, const SceneLds& sc, RNG& rng, const float* dirs,
+                                                   v3 origin, Counters& cnt)
+{
+    v3 res_color = mk(0, 0, 0), res_em = mk(0, 0, 0);
+    float res_st = 0.0f;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {                                            // renderer.h:167-195
+        v3 dir = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+        PathOut p = trace_path<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, RNG, BATCH>(sc, rng, origin, dir, a.max_depth, cnt, a.fault);
+        // renderer.h:169: color / vec3(maxDepth); x / 1.0f == x, and most paths end at depth 1
+        v3 pc = p.color;
+        if (p.maxDepth != 1) { float md = (float)p.maxDepth; pc = mk(pc.x / md, pc.y / md, pc.z / md); }
+        res_color = res_color + pc;
+        if (EMISSION) {
+            res_em = res_em + p.emission;
+            res_st = (k == 0) ? p.strength : gmax(res_st, p.strength);
+        }
+    }
+    SampleOut o;
+    res_color = res_color * 0.25f;
+    o.color = mk(clamp01(res_color.x), clamp01(res_color.y), clamp01(res_color.z));               // main.cpp:313
+    o.emission = mk(0, 0, 0); o.strength = 0.0f;
+    if (EMISSION) {
+        res_em = res_em * 0.25f;
+        o.emission = mk(clamp01(res_em.x), clamp01(res_em.y), clamp01(res_em.z));
+        o.strength = res_st;
+    }
+    return o;
+}
+
+// pixel::Set / emissionPixel::Set of the sample sums (main.cpp:318-319 -> structs.h:12-17,39-43)
+template <bool EMISSION>
+__device__ __forceinline__ void store_pixel(const KernelArgs& a, size_t o, v3 acc_color, v3 acc_em, float acc_st)
+{
+    const float n = (float)a.samples;
+    if (a.rgb) {
+        a.rgb[o * 3 + 0] = quantise(acc_color.x / n);
+        a.rgb[o * 3 + 1] = quantise(acc_color.y / n);
+        a.rgb[o * 3 + 2] = quantise(acc_color.z / n);
+    }
+    if (EMISSION && a.emission)
+        a.emission[o] = make_float4(acc_em.x / n, acc_em.y / n, acc_em.z / n, acc_st / n);
+}
+
+// Hands a long pixel over to heavy_kernel (DESIGN.md "sample-parallel pixels").  Called after the first
+// RT_HEAVY_PROBE samples, which drew d0 numbers each: the generator state at the start of sample s is recorded for
+// every later s, on the guess that every sample draws d0 numbers; heavy_kernel checks the guess.  Table entry: 31 words + front slot, RT_HEAVY_SAMPLES
+// entries per pixel; record: pixel, d0, the sums over the samples done.  Returns false when the table is full (the
+// caller then carries on itself).
+template <class RNG>
+__device__ __forceinline__ bool heavy_handover(const KernelArgs& a, RNG& rng, unsigned int pixel, unsigned int d0,
+                                               v3 acc_color, v3 acc_em, float acc_st)
+{
+    const unsigned int h = atomicAdd(a.heavy_count, 1u);
+    if (h >= (unsigned int)a.heavy_cap) return false;
+    unsigned int* rec = a.heavy_rec + (size_t)h * RT_HEAVY_REC_WORDS;
+    rec[0] = pixel; rec[1] = d0;
+    rec[2] = __float_as_uint(acc_color.x); rec[3] = __float_as_uint(acc_color.y); rec[4] = __float_as_uint(acc_color.z);
+    rec[5] = __float_as_uint(acc_em.x); rec[6] = __float_as_uint(acc_em.y); rec[7] = __float_as_uint(acc_em.z);
+    rec[8] = __float_as_uint(acc_st);
+    unsigned int* tab = a.heavy_state + (size_t)h * (RT_HEAVY_SAMPLES * 32);
+    for (int s = RT_HEAVY_PROBE; s < a.samples; ++s) {
+        unsigned int* e = tab + s * 32;
+        for (int k = 0; k < 31; ++k) e[k] = rng.r[k * RNG::stride];
+        e[31] = (unsigned int)rng.f;
+        if (s + 1 < a.samples)
+            for (unsigned int i = 0; i < d0; ++i) (void)rng.next();
+    }
+    return true;
+}
+
+// The per-pixel driver (main.cpp:298-319 == main.cu:38-67) over AntiAliasing (renderer.h:138-201), for pixel
+// (x, y) of the frame = column x of packed output row r.
+// LDS_RNG: the generator's 31 words live in LDS at rng_lds (slot-major) instead of in scratch.  HEAVY: pixels whose
+// first sample shows a long path are handed to heavy_kernel.
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, bool LDS_RNG, int BATCH, bool HEAVY>
+__device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds& sc, float* dirs, unsigned int* rng_lds,
+                                             int x, int y, int r, Counters& cnt)
+{
+    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+    typedef RngT<LDS_RNG ? BLOCK : 1> RNG;
+    unsigned int rng_words[LDS_RNG ? 1 : 31];
+    RNG rng;
+    rng.init(LDS_RNG ? rng_lds : rng_words, a.seed_base + (unsigned int)(x + y * a.width));   // rand.h:7, main.cpp:304
+
+    // AntiAliasing is called with the same (u, v) for every sample (main.cpp:312), so the four primary directions
+    // are per-pixel constants: computed once, parked in LDS (12 words per thread, word j of thread t at [j*BLOCK + t]).
+    primary_directions(a, dirs, x, y);
+
+    const size_t o = (size_t)x + (size_t)r * a.width;
+    v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0);
+    float acc_st = 0.0f;
+    unsigned int d0 = 0;
+    bool steady = true;
+    for (int s = 0; s < a.samples; ++s) {
+        SampleOut so = render_sample<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, RNG, BATCH>(a, sc, rng, dirs, origin, cnt);
+        acc_color = acc_color + so.color;
+        if (EMISSION) { acc_em = acc_em + so.emission; acc_st += so.strength; }
+        if (HEAVY && a.heavy_cap > 0 && s < RT_HEAVY_PROBE) {
+            // the first samples all drew the same count: a path whose shape does not hang on the numbers drawn, probably
+            if (s == 0) d0 = rng.ndraws;
+            steady = steady && rng.ndraws == (unsigned int)(s + 1) * d0;
+            if (s == RT_HEAVY_PROBE - 1 && steady && d0 > 0
+                && (unsigned long long)d0 * (unsigned int)(a.samples - RT_HEAVY_PROBE) >= (unsigned long long)a.heavy_min_work
+                && heavy_handover(a, rng, (unsigned int)o, d0, acc_color, acc_em, acc_st))
+                return;
+        }
+    }
+    store_pixel<EMISSION>(a, o, acc_color, acc_em, acc_st);
+}
+
+template <bool HAS_NONSPHERE, int BATCH = 1>
+__device__ __forceinline__ int primary_closest(const SceneLds& sc, v3 ro, v3 rd, float& dist)
+{
+    Counters none = { 0, 0, 0, 0, 0 };
+    if (!HAS_NONSPHERE) return closest_hit_primary<false, BATCH>(sc, rd, dist, none);
+    return closest_hit<HAS_NONSPHERE, false, BATCH>(sc, ro, rd, dist, none);
+}
+
+// classify_kernel: key[pixel] = 0 when none of the pixel's four primary rays hits a material that bounces
+// (reflection > 0 or refraction > 0, renderer.h:74,93; bounces need depth 1 <= max_depth, renderer.h:68), else
+// 1 + the first such material.  Primary rays are the same for every sample (same u, v; no draw happens before the
+// first hit), so the key holds for the whole pixel.  hist[key] counts pixels per key.
+template <bool HAS_NONSPHERE>
+__global__ __launch_bounds__(BLOCK) void classify_kernel(KernelArgs a)
+{
+    extern __shared__ float4 lds[];
+    __shared__ unsigned int l_hist[RT_MAX_KEYS];
+    SceneLds sc;
+    float* lds_free;
+    stage_scene(a, lds, sc, lds_free);
+    for (int i = threadIdx.x; i < RT_MAX_KEYS; i += BLOCK) l_hist[i] = 0;
+    __syncthreads();
+
+    const PixelId p = tiled_pixel(a);
+    if (p.active) {
+        float* dirs = lds_free + threadIdx.x;
+        primary_directions(a, dirs, p.x, p.y);
+        const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+        int key = 0;
+#pragma unroll 1
+        for (int k = 0; k < 4 && key == 0; ++k) {
+            v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+            float dist;
+            int bi = primary_closest<HAS_NONSPHERE>(sc, origin, rd, dist);
+            if (bi >= 0) {
+                int m = rec_material(sc.hrec[2 * bi + 1]);
+                if (sc.mats[10 * m + 4] > 0 || sc.mats[10 * m + 5] > 0) key = m + 1;
+            }
+        }
+        a.keys[(size_t)p.x + (size_t)p.r * a.width] = (unsigned short)key;
+        if (key) atomicAdd(&l_hist[key], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RT_MAX_KEYS; i += BLOCK)
+        if (l_hist[i]) atomicAdd(&a.hist[i], l_hist[i]);
+}
+
+// Exclusive scan of hist[1..] into cursor[] (one workgroup; at most 257 keys); cursor[0] receives the total.
+__global__ void scan_kernel(const unsigned int* __restrict__ hist, unsigned int* __restrict__ cursor)
+{
+    if (threadIdx.x == 0) {
+        unsigned int s = 0;
+        for (int k = 1; k < RT_MAX_KEYS; ++k) { cursor[k] = s; s += hist[k]; }
+        cursor[0] = s;
+    }
+}
+
+// list[cursor[key]++] = pixel, for every pixel with key != 0: the list comes out grouped by material, so a wave of
+// render_kernel works on pixels whose paths look alike.
+__global__ __launch_bounds__(BLOCK) void scatter_kernel(const unsigned short* __restrict__ keys, unsigned int n,
+                                                        unsigned int* __restrict__ cursor, unsigned int* __restrict__ list)
+{
+    // ranks within the workgroup's chunk come from LDS counters; one global reservation per key and workgroup
+    __shared__ unsigned int l_cnt[RT_MAX_KEYS], l_base[RT_MAX_KEYS];
+    for (int i = threadIdx.x; i < RT_MAX_KEYS; i += BLOCK) l_cnt[i] = 0;
+    __syncthreads();
+    const unsigned int chunk = blockIdx.x * (BLOCK * 8);
+    unsigned int k[8], rank[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned int i = chunk + j * BLOCK + threadIdx.x;
+        k[j] = i < n ? keys[i] : 0u;
+        rank[j] = k[j] ? atomicAdd(&l_cnt[k[j]], 1u) : 0u;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RT_MAX_KEYS; i += BLOCK)
+        if (l_cnt[i]) l_base[i] = atomicAdd(&cursor[i], l_cnt[i]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (k[j]) list[l_base[k[j]] + rank[j]] = chunk + j * BLOCK + threadIdx.x;
+}
+
+// direct_kernel: the per-pixel driver for pixels whose primary rays never bounce.  TraceRay then is: closest hit ->
+// sky (renderer.h:40-50) or one shading (renderer.h:55-66) with multiplier 1 and maxDepth = depth = 1
+// (renderer.h:128-132), so color / vec3(maxDepth) is color / 1 and no random number is drawn.
+template <bool EMISSION, bool HAS_NONSPHERE>
+__global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
+{
+    extern __shared__ float4 lds[];
+    SceneLds sc;
+    float* lds_free;
+    stage_scene(a, lds, sc, lds_free);
+
+    const PixelId p = tiled_pixel(a);
+    if (!p.active) return;
+    const size_t o = (size_t)p.x + (size_t)p.r * a.width;
+    if (a.keys && a.keys[o] != 0) return;              // render_kernel has this pixel
+
+    float* dirs = lds_free + threadIdx.x;
+    primary_directions(a, dirs, p.x, p.y);
+    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+    Counters none = { 0, 0, 0, 0, 0 };
 
     v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0);
     float acc_st = 0.0f;
@@ -241,16 +525,28 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
         v3 res_color = mk(0, 0, 0), res_em = mk(0, 0, 0);
         float res_st = 0.0f;
 #pragma unroll 1
-        for (int k = 0; k < a.rays_per_sample; ++k) {                        // renderer.h:167-195 (4; 1 in the cost pre-pass)
-            v3 dir = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
-            PathOut p = trace_path<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND>(sc, rng, origin, dir, a.max_depth, cnt, a.fault);
-            // renderer.h:169: color / vec3(maxDepth); x / 1.0f == x, and most paths end at depth 1
-            v3 pc = p.color;
-            if (p.maxDepth != 1) { float md = (float)p.maxDepth; pc = mk(pc.x / md, pc.y / md, pc.z / md); }
-            res_color = res_color + pc;
+        for (int k = 0; k < 4; ++k) {                                        // renderer.h:167-195
+            v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+            float dist;
+            int bi = primary_closest<HAS_NONSPHERE, RT_DIRECT_BATCH>(sc, origin, rd, dist);
+            v3 color, em = mk(0, 0, 0);
+            float st = 0.0f;
+            if (bi < 0) {                                                    // renderer.h:47-49
+                float aa = (rd.y + 1.0f) * 0.5f;
+                float w = 1.0f - aa;
+                color = mk(w + aa * 0.2f, w + aa * 0.3f, w + aa * 0.8f) * 1.0f;
+            } else {
+                Hit h = hit_record(sc, bi, origin, rd, dist);
+                v3 offPosition = h.position + h.normal * 0.005f;             // renderer.h:55
+                float intensity = light_intensity<HAS_NONSPHERE, false, true, RT_DIRECT_BATCH>(sc, offPosition, h.normal, none);
+                const float* m = sc.mats + 10 * h.material;
+                color = (mk(m[0], m[1], m[2]) * intensity) * 1.0f;           // renderer.h:64
+                if (EMISSION) { em = mk(m[6], m[7], m[8]); st = m[9]; }
+            }
+            res_color = res_color + color;                                   // renderer.h:169, maxDepth == 1
             if (EMISSION) {
-                res_em = res_em + p.emission;
-                res_st = (k == 0) ? p.strength : gmax(res_st, p.strength);
+                res_em = res_em + em;
+                res_st = (k == 0) ? st : gmax(res_st, st);
             }
         }
         res_color = res_color * 0.25f;
@@ -261,9 +557,7 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
             acc_st += res_st;
         }
     }
-
     const float n = (float)a.samples;
-    const size_t o = (size_t)x + (size_t)r * a.width;
     if (a.rgb) {                                                             // main.cpp:318 -> structs.h:12-17
         a.rgb[o * 3 + 0] = quantise(acc_color.x / n);
         a.rgb[o * 3 + 1] = quantise(acc_color.y / n);
@@ -273,68 +567,117 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
         a.emission[o] = make_float4(acc_em.x / n, acc_em.y / n, acc_em.z / n, acc_st / n);
 }
 
-// One workgroup = one 16x16 tile (four 8x8 waves).  a.order (optional) maps launch order to tile index so that
-// expensive tiles start first; a.tile_cost (counting builds only) receives the tile's primitive-test count instead of
-// the global tallies -- that is the cost pre-pass (DESIGN.md "tile order").
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
-__global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void render_kernel(KernelArgs a)
+// render_kernel: the general per-pixel driver.  LISTED: over the pixel list built by classify / scatter, at raised
+// wave priority (these are the long pixels; the direct kernel's waves fill in around them).  Otherwise over 16x16
+// tiles of every pixel (tallying builds).
+template <bool LISTED, bool LDS_RNG, bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
+__global__ __launch_bounds__(BLOCK, LISTED ? RT_LISTED_WAVES : RT_MIN_WAVES) void render_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
     SceneLds sc;
     float* lds_free;
     stage_scene(a, lds, sc, lds_free);
+    if (LISTED) __builtin_amdgcn_s_setprio(3);
 
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int tile = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int r = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool active = x < a.width && r < a.rows;
-    const int y = a.band_rows > 0 ? a.row0 + (r / a.band_rows) * a.band_stride + (r % a.band_rows) : a.row0 + r;
-
+    const PixelId p = LISTED ? listed_pixel(a) : tiled_pixel(a);
     Counters cnt = { 0, 0, 0, 0, 0 };
-    if (active)
-        render_pixel<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND>(a, sc, lds_free + tid, x, y, r, cnt);
-
-    if (COUNT) {
-        if (a.tile_cost) {
-            unsigned int* acc = (unsigned int*)(lds_free + 12 * BLOCK);
-            if (tid == 0) *acc = 0;
-            __syncthreads();
-            if (active) atomicAdd(acc, cnt.tests);
-            __syncthreads();
-            if (tid == 0) a.tile_cost[tile] = *acc;
-        } else if (active) {
-            flush_counters(a, cnt);
-        }
-    }
+    // the listed kernel has few, long waves: it trades LDS and registers for shorter dependent chains
+    constexpr int BATCH = LISTED ? RT_LISTED_BATCH : 1;
+    unsigned int* rng_lds = (unsigned int*)(lds_free + 12 * BLOCK) + threadIdx.x;
+    if (p.active)
+        render_pixel<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, LDS_RNG, BATCH, LISTED>(a, sc, lds_free + threadIdx.x, rng_lds, p.x, p.y, p.r, cnt);
+    if (COUNT && p.active) flush_counters(a, cnt);
 }
 
-// Launch order from tile costs: counting sort by a 7-bit log-scale key, most expensive first.  One workgroup.
-__global__ __launch_bounds__(1024) void order_kernel(const unsigned int* __restrict__ cost, int n, int* __restrict__ order)
+// heavy_kernel: one wave per handed-over pixel, one lane per sample (DESIGN.md "sample-parallel pixels").  A pixel's
+// samples share one rand() stream, so sample s can only start where sample s-1 stopped; the hand-over guessed those
+// starting states d0 draws apart.  Every lane traces its sample from its guessed state and counts its draws: up to and
+// including the first lane whose count is not d0 the guesses were right.  That lane's final state is the true start of
+// the next sample; it re-guesses the later lanes' states from there and they trace again, until all samples stand.
+// The sample results are then added in sample order by one lane, like the serial loop does.
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
+__global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArgs a)
 {
-    __shared__ unsigned int hist[128];
-    __shared__ unsigned int start[128];
-    const int tid = threadIdx.x;
-    if (tid < 128) hist[tid] = 0;
-    __syncthreads();
-    auto key = [](unsigned int c) -> int {
-        // descending cost -> ascending key: 4 buckets per octave
-        if (c == 0) return 127;
-        int e = 31 - __clz(c);
-        int m = e >= 2 ? (int)((c >> (e - 2)) & 3) : 0;
-        int k = e * 4 + m;                 // 0 .. 127
-        return 127 - (k > 127 ? 127 : k);
-    };
-    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[key(cost[i])], 1u);
-    __syncthreads();
-    if (tid == 0) {
-        unsigned int s = 0;
-        for (int k = 0; k < 128; ++k) { start[k] = s; s += hist[k]; }
+    extern __shared__ float4 lds[];
+    unsigned int count = *a.heavy_count;
+    if (count > (unsigned int)a.heavy_cap) count = (unsigned int)a.heavy_cap;
+    if (blockIdx.x * (BLOCK / 64) >= count) return;                         // whole workgroup: before any barrier
+    SceneLds sc;
+    float* lds_free;
+    stage_scene(a, lds, sc, lds_free);
+    __builtin_amdgcn_s_setprio(3);
+
+    const int lane = threadIdx.x & 63;
+    const unsigned int h = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (h >= count) return;
+    const unsigned int* rec = a.heavy_rec + (size_t)h * RT_HEAVY_REC_WORDS;
+    const unsigned int o = rec[0], d0 = rec[1];
+    const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
+    const int y = frame_row(a, r);
+    float* dirs = lds_free + threadIdx.x;
+    primary_directions(a, dirs, x, y);                                       // every lane: the same pixel
+    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+
+    // generator words in LDS: word k of thread t at [k*BLOCK + t], k = 31 holds the front slot while states are passed
+    unsigned int* slots = (unsigned int*)(lds_free + 12 * BLOCK) + threadIdx.x;
+    const bool active = lane >= RT_HEAVY_PROBE && lane < a.samples;      // the first samples came with the hand-over
+    typedef RngT<BLOCK> RNG;
+    RNG rng;
+    rng.init(slots, 0u);
+    rng.seeded = true;
+    if (active) {
+        const unsigned int* e = a.heavy_state + ((size_t)h * RT_HEAVY_SAMPLES + lane) * 32;
+        for (int k = 0; k < 31; ++k) slots[k * BLOCK] = e[k];
+        rng.f = (int)e[31];
     }
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) order[atomicAdd(&start[key(cost[i])], 1u)] = i;
+
+    Counters cnt = { 0, 0, 0, 0, 0 };
+    SampleOut so;
+    so.color = mk(0, 0, 0); so.emission = mk(0, 0, 0); so.strength = 0.0f;
+    int first = RT_HEAVY_PROBE;         // samples below `first` stand
+    for (int round = 0;; ++round) {
+        const bool mine = active && lane >= first;
+        if (mine) {
+            rng.ndraws = 0;
+            so = render_sample<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, RNG, RT_LISTED_BATCH>(a, sc, rng, dirs, origin, cnt);
+        }
+        const unsigned long long off = __ballot(mine && rng.ndraws != d0);
+        if (off == 0ull) break;
+        const int sb = __ffsll((long long)off) - 1;      // sample sb started right, so it stands; sb + 1 starts where it stopped
+        if (sb + 1 >= a.samples) break;
+        if (round == RT_HEAVY_ROUNDS || __popcll(off) > RT_HEAVY_ROUNDS - round) {
+            // the guess keeps failing: this pixel's draws depend on the numbers drawn; leave it to the serial kernel
+            if (lane == 0) a.fallback_list[atomicAdd(a.fallback_count, 1u)] = o;
+            return;
+        }
+        if (lane == sb) {
+            unsigned int* dst = slots;
+            for (int s = sb + 1; s < a.samples; ++s) {
+                ++dst;                                   // thread t + 1's slots
+                for (int k = 0; k < 31; ++k) dst[k * BLOCK] = slots[k * BLOCK];
+                dst[31 * BLOCK] = (unsigned int)rng.f;
+                if (s + 1 < a.samples)
+                    for (unsigned int i = 0; i < d0; ++i) (void)rng.next();
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (active && lane > sb) rng.f = (int)slots[31 * BLOCK];
+        first = sb + 1;
+    }
+
+    // main.cpp:313-315: the sums run in sample order
+    v3 acc_color = mk(__uint_as_float(rec[2]), __uint_as_float(rec[3]), __uint_as_float(rec[4]));
+    v3 acc_em = mk(__uint_as_float(rec[5]), __uint_as_float(rec[6]), __uint_as_float(rec[7]));
+    float acc_st = __uint_as_float(rec[8]);
+    for (int s = RT_HEAVY_PROBE; s < a.samples; ++s) {
+        acc_color = acc_color + mk(__shfl(so.color.x, s), __shfl(so.color.y, s), __shfl(so.color.z, s));
+        if (EMISSION) {
+            acc_em = acc_em + mk(__shfl(so.emission.x, s), __shfl(so.emission.y, s), __shfl(so.emission.z, s));
+            acc_st += __shfl(so.strength, s);
+        }
+    }
+    if (lane == 0) store_pixel<EMISSION>(a, (size_t)o, acc_color, acc_em, acc_st);
 }
 
 // MaxRayDistance (renderer.h:204-219) per pixel, as tests/singlePixel.cpp:74-83 drives it.
@@ -444,23 +787,16 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 // ---- launchers ------------------------------------------------------------------------------------------------
 using namespace rt;
 
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
-static hipError_t launch_one(const KernelArgs& a, int tiles, size_t lds_bytes, hipStream_t stream)
+template <class K>
+static hipError_t launch_with_lds(K k, const KernelArgs& a, int blocks, size_t lds_bytes, hipStream_t stream)
 {
-    auto k = render_kernel<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND>;
+    if (blocks <= 0) return hipSuccess;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(BLOCK), lds_bytes, stream, a);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
     return hipGetLastError();
-}
-
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE>
-static hipError_t launch_depth(const KernelArgs& a, bool deep, int tiles, size_t lds, hipStream_t s)
-{
-    if (deep) return launch_one<EMISSION, MIXED, HAS_NONSPHERE, false, true, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, s);
-    return launch_one<EMISSION, MIXED, HAS_NONSPHERE, false, true, RT_STACK_SHALLOW, RT_PEND_SHALLOW>(a, tiles, lds, s);
 }
 
 size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat)
@@ -469,19 +805,34 @@ size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat)
     return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)12 * BLOCK * 4 + 16;
 }
 
+// the listed render_kernel also keeps the generators there: 31 words per thread
+static size_t listed_lds_bytes(int n_hit, int n_lights, int n_mat)
+{
+    return rt_launch_lds_bytes(n_hit, n_lights, n_mat) + (size_t)32 * BLOCK * 4;
+}
+
+template <bool LISTED, bool LDS_RNG, bool EMISSION, bool MIXED, bool HAS_NONSPHERE>
+static hipError_t launch_general(const KernelArgs& a, bool deep, int blocks, size_t lds, hipStream_t s)
+{
+    if (deep) return launch_with_lds(render_kernel<LISTED, LDS_RNG, EMISSION, MIXED, HAS_NONSPHERE, false, true, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, s);
+    return launch_with_lds(render_kernel<LISTED, LDS_RNG, EMISSION, MIXED, HAS_NONSPHERE, false, true, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, s);
+}
+
+// The general per-pixel kernel: over the pixel list (a.list / a.list_count) when t.listed, else over all tiles.
 hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
 {
-    const int tiles = a.tiles_x * a.tiles_y;
-    if (tiles <= 0) return hipSuccess;
-    const size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+    const int blocks = t.listed ? (a.list_count + BLOCK - 1) / BLOCK : a.tiles_x * a.tiles_y;
+    size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+    // large scenes leave no room for the generators next to the staged records: they stay in scratch then
+    const bool lds_rng = t.listed && RT_LISTED_LDS_RNG && listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat) <= 160 * 1024;
+    if (lds_rng) lds = listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
     // the tally builds are the most general ones: emission, mixed, all primitive types, deep stack
-    if (t.count && !t.prune) return launch_one<true, true, true, true, false, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, stream);
-    if (t.count && !t.cost) return launch_one<true, true, true, true, true, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, stream);
-    if (t.count) {   // cost pre-pass: tallies primitive tests per tile, no emission bookkeeping
-        if (!t.mixed && !t.nonsphere && !t.deep) return launch_one<false, false, false, true, true, RT_STACK_SHALLOW, RT_PEND_SHALLOW>(a, tiles, lds, stream);
-        return launch_one<false, true, true, true, true, RT_STACK_DEEP, RT_PEND_DEEP>(a, tiles, lds, stream);
-    }
-#define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N) return launch_depth<E, M, N>(a, t.deep, tiles, lds, stream);
+    if (t.count && !t.prune) return launch_with_lds(render_kernel<false, false, true, true, true, true, false, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream);
+    if (t.count)             return launch_with_lds(render_kernel<false, false, true, true, true, true, true, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream);
+#define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N) \
+        return !t.listed ? launch_general<false, false, E, M, N>(a, t.deep, blocks, lds, stream) \
+             : lds_rng   ? launch_general<true, true, E, M, N>(a, t.deep, blocks, lds, stream)   \
+                         : launch_general<true, false, E, M, N>(a, t.deep, blocks, lds, stream);
     RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
     RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)
     RT_DISPATCH(true, false, false)  RT_DISPATCH(true, false, true)
@@ -490,10 +841,50 @@ hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStrea
     return hipErrorInvalidValue;
 }
 
-hipError_t rt_launch_order(const unsigned int* cost, int n, int* order, hipStream_t stream)
+// classify (keys + histogram) -> scan -> scatter (the pixel list).  a.keys / a.hist / cursor / list are device buffers.
+hipError_t rt_launch_classify(const KernelArgs& a, const LaunchTraits& t, unsigned int* cursor, unsigned int* list, hipStream_t stream)
 {
-    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, cost, n, order);
+    const int tiles = a.tiles_x * a.tiles_y;
+    const size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+    hipError_t e = t.nonsphere ? launch_with_lds(classify_kernel<true>, a, tiles, lds, stream)
+                               : launch_with_lds(classify_kernel<false>, a, tiles, lds, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, stream, (const unsigned int*)a.hist, cursor);
+    const unsigned int n = (unsigned int)a.width * (unsigned int)a.rows;
+    int blocks = (int)((n + BLOCK * 8 - 1) / (BLOCK * 8));
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(BLOCK), 0, stream, (const unsigned short*)a.keys, n, cursor, list);
     return hipGetLastError();
+}
+
+hipError_t rt_launch_direct(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
+{
+    const int tiles = a.tiles_x * a.tiles_y;
+    const size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+    if (t.emission) return t.nonsphere ? launch_with_lds(direct_kernel<true, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<true, false>, a, tiles, lds, stream);
+    return t.nonsphere ? launch_with_lds(direct_kernel<false, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<false, false>, a, tiles, lds, stream);
+}
+
+bool rt_launch_heavy_fits(int n_hit, int n_lights, int n_mat)
+{
+    return listed_lds_bytes(n_hit, n_lights, n_mat) <= 160 * 1024;
+}
+
+// One wave per pixel handed over by the listed render_kernel; the grid covers the table, workgroups past the count
+// the listed kernel left in a.heavy_count leave at once.
+hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
+{
+    const int blocks = (a.heavy_cap + BLOCK / 64 - 1) / (BLOCK / 64);
+    const size_t lds = listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+#define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N) \
+        return t.deep ? launch_with_lds(heavy_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream) \
+                      : launch_with_lds(heavy_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, stream);
+    RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
+    RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)
+    RT_DISPATCH(true, false, false)  RT_DISPATCH(true, false, true)
+    RT_DISPATCH(true, true, false)   RT_DISPATCH(true, true, true)
+#undef RT_DISPATCH
+    return hipErrorInvalidValue;
 }
 
 hipError_t rt_launch_probe(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)

@@ -8,6 +8,10 @@
 // one to depth, renderer.h:68,82) plus the refraction parents, whose count is bounded by multiplier *= 0.9f until
 // < 0.001f (renderer.h:30,118): 66 in float arithmetic (rt_abi.cpp recomputes it).  Shallow serves max_depth <= 14,
 // deep serves RT_MAX_DEPTH (64).
+// pixel classes: 0 = direct, 1 + material index (RT_MAX_MATERIALS = 256)
+#define RT_MAX_KEYS 257
+#define RT_HEAVY_REC_WORDS 12
+
 #define RT_STACK_SHALLOW 80
 #define RT_PEND_SHALLOW  15
 #define RT_STACK_DEEP    132
@@ -16,7 +20,6 @@
 struct KernelArgs {
     float cam[35];               // position, inverse projection, inverse view (rt_camera35f)
     int width, height, samples, max_depth;
-    int rays_per_sample;         // 4 (renderer.h:167-195); the cost pre-pass traces only the first one
     unsigned int seed_base;      // low 32 bits: srand() takes an unsigned int (rand.h:7)
     int row0, rows, band_rows, band_stride;
     int tiles_x, tiles_y;
@@ -29,8 +32,19 @@ struct KernelArgs {
     float4* emission;            // rows * width, or null
     unsigned long long* counters;// 5 words (closest, shadow, tests, draws, shaded), or null
     int* fault;                  // set to 1 by a kernel whose bounce stack would overflow
-    const int* order;            // launch order -> tile index (tiles_x * tiles_y entries), or null = identity
-    unsigned int* tile_cost;     // counting builds: per-tile primitive-test count instead of the global tallies
+    unsigned short* keys;        // rows * width pixel classes (0 = direct, 1 + material = general), or null
+    unsigned int* hist;          // RT_MAX_KEYS pixel counts per key
+    const unsigned int* list;    // pixel list of the listed render_kernel (indices into the packed output)
+    int list_count;
+    const unsigned int* list_count_dev;  // if not null: the list length lives on the device (list_count = capacity)
+    // sample-parallel pixels (listed render_kernel -> heavy_kernel); heavy_cap == 0 switches the hand-over off
+    unsigned int* heavy_count;   // pixels handed over (may run past heavy_cap: those were not handed over)
+    unsigned int* heavy_rec;     // heavy_cap x RT_HEAVY_REC_WORDS: pixel, draws per sample, sums over the samples done
+    unsigned int* heavy_state;   // heavy_cap x 64 samples x 32 words: generator state at the start of each sample
+    int heavy_cap;
+    unsigned int heavy_min_work; // hand over when draws(sample 0) * (samples left) reaches this
+    unsigned int* fallback_count;// pixels heavy_kernel gave up on ...
+    unsigned int* fallback_list; // ... for a serial pass of the listed render_kernel (heavy_cap entries)
 };
 
 struct LaunchTraits {
@@ -39,13 +53,16 @@ struct LaunchTraits {
     bool nonsphere;  // scene holds planes or cubes
     bool deep;       // max_depth needs the deep stack
     bool count;      // tally queries
-    bool cost;       // with count: per-tile cost pre-pass (writes KernelArgs::tile_cost)
+    bool listed;     // render_kernel over KernelArgs::list instead of over all tiles
     bool prune;      // with count: tally the production kernel's pruned shadow queries instead of the reference's
 };
 
 size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat);
 hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
-hipError_t rt_launch_order(const unsigned int* cost, int n, int* order, hipStream_t stream);
+hipError_t rt_launch_classify(const KernelArgs& a, const LaunchTraits& t, unsigned int* cursor, unsigned int* list, hipStream_t stream);
+hipError_t rt_launch_direct(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
+bool rt_launch_heavy_fits(int n_hit, int n_lights, int n_mat);
+hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_probe(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_deinterleave(const void* gathered, void* frame, int row_bytes, int height, int band_rows,
                                   int nranks, int rows_per_rank, hipStream_t stream);
