@@ -23,6 +23,8 @@ struct rt_ctx {
     int device = -1;
     hipStream_t stream = nullptr;      // everything but the listed general kernel
     hipStream_t stream2 = nullptr;     // the listed general kernel, beside the direct kernel
+    hipStream_t stream3 = nullptr;     // its second launch (RT_MODE_REST) when long pixels are handed over
+    hipEvent_t ev_rest = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, ev_list = nullptr, ev_gen = nullptr;
     float last_ms = 0.0f, last_total_ms = 0.0f;
     int last_hip = 0;
@@ -126,7 +128,7 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
     a.hrec = ctx->d_hrec; a.lights = ctx->d_lights; a.mats = ctx->d_mats;
     a.rgb = nullptr; a.emission = nullptr; a.counters = ctx->d_counters; a.fault = ctx->d_fault;
     a.keys = nullptr; a.hist = nullptr; a.list = nullptr; a.list_count = 0; a.list_count_dev = nullptr;
-    a.fallback_count = nullptr; a.fallback_list = nullptr;
+    a.fallback_count = nullptr; a.fallback_list = nullptr; a.listed_mode = 0;
     a.heavy_count = nullptr; a.heavy_rec = nullptr; a.heavy_state = nullptr; a.heavy_cap = 0; a.heavy_min_work = 0;
     a.prim = ctx->d_prim;
 }
@@ -194,6 +196,8 @@ int rt_create(rt_ctx** out, int device_ordinal)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_list, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gen, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_rest, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, RT_DEV_WORDS_BYTES);
     if (e != hipSuccess) { rt_destroy(ctx); return RT_ERR_HIP; }
     ctx->d_fault = (int*)(ctx->d_counters + 5);
@@ -216,6 +220,8 @@ void rt_destroy(rt_ctx* ctx)
     if (ctx->ev_list) (void)hipEventDestroy(ctx->ev_list);
     if (ctx->ev_gen) (void)hipEventDestroy(ctx->ev_gen);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_rest) (void)hipEventDestroy(ctx->ev_rest);
+    if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
     if (ctx->d_classes) (void)hipFree(ctx->d_classes);
     if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -380,6 +386,7 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
         // stream; all other pixels need no RNG, stack or scratch and go to the direct kernel.
         const bool bounces = ctx->any_bounce && p->max_depth >= 1;       // renderer.h:68: depth 1 <= maxTotalDepth
         unsigned int n_listed = 0;
+        bool rest = false;
         if (bounces) {
             const size_t keys_bytes = (npix * 2 + 15) & ~(size_t)15;
             rc = grow(ctx, &ctx->d_classes, &ctx->classes_bytes, keys_bytes + npix * 4 + 2 * RT_MAX_KEYS * 4);
@@ -417,14 +424,19 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                     HIP_TRY(ctx, hipMemsetAsync(g2.heavy_count, 0, 16, ctx->stream2));
                 }
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_list, 0));
-                HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream2));
                 if (g2.heavy_cap > 0) {
+                    // the steady long pixels: first samples, hand-over, heavy kernel, resume kernel ...
+                    g2.listed_mode = RT_MODE_STEADY;
+                    HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream2));
                     HIP_TRY(ctx, rt_launch_heavy(g2, tg, ctx->stream2));
-                    // pixels the heavy kernel gave up on: the listed kernel again, without hand-over
-                    KernelArgs g3 = g2;
-                    g3.list = g2.fallback_list; g3.list_count = g2.heavy_cap; g3.list_count_dev = g2.fallback_count;
-                    g3.heavy_cap = 0;
-                    HIP_TRY(ctx, rt_launch_render(g3, tg, ctx->stream2));
+                    // ... and beside them all other listed pixels
+                    g2.listed_mode = RT_MODE_REST;
+                    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_list, 0));
+                    HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream3));
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_rest, ctx->stream3));
+                    rest = true;
+                } else {
+                    HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream2));
                 }
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_gen, ctx->stream2));
             }
@@ -432,6 +444,7 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
         HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
         if (n_listed < npix) HIP_TRY(ctx, rt_launch_direct(a, t, ctx->stream));
         if (n_listed > 0) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gen, 0));
+        if (rest) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_rest, 0));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 

@@ -403,13 +403,18 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
         acc_color = acc_color + so.color;
         if (EMISSION) { acc_em = acc_em + so.emission; acc_st += so.strength; }
         if (HEAVY && a.heavy_cap > 0 && s < RT_HEAVY_PROBE) {
-            // the first samples all drew the same count: a path whose shape does not hang on the numbers drawn, probably
+            // the first samples all drew the same count: a path whose shape does not hang on the numbers drawn, probably.
+            // Two launches of this kernel share the list: one owns the steady long pixels and hands them over, the
+            // other owns the rest; both learn which is which from the same first samples.
             if (s == 0) d0 = rng.ndraws;
             steady = steady && rng.ndraws == (unsigned int)(s + 1) * d0;
-            if (s == RT_HEAVY_PROBE - 1 && steady && d0 > 0
-                && (unsigned long long)d0 * (unsigned int)(a.samples - RT_HEAVY_PROBE) >= (unsigned long long)a.heavy_min_work
-                && heavy_handover(a, rng, (unsigned int)o, d0, acc_color, acc_em, acc_st))
-                return;
+            if (s == RT_HEAVY_PROBE - 1) {
+                const bool eligible = steady && d0 > 0
+                    && (unsigned long long)d0 * (unsigned int)(a.samples - RT_HEAVY_PROBE) >= (unsigned long long)a.heavy_min_work;
+                if (a.listed_mode == RT_MODE_REST) { if (eligible) return; }
+                else if (!eligible) return;
+                else if (heavy_handover(a, rng, (unsigned int)o, d0, acc_color, acc_em, acc_st)) return;
+            }
         }
     }
     store_pixel<EMISSION>(a, o, acc_color, acc_em, acc_st);
@@ -646,8 +651,29 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArg
         const int sb = __ffsll((long long)off) - 1;      // sample sb started right, so it stands; sb + 1 starts where it stopped
         if (sb + 1 >= a.samples) break;
         if (round == RT_HEAVY_ROUNDS || __popcll(off) > RT_HEAVY_ROUNDS - round) {
-            // the guess keeps failing: this pixel's draws depend on the numbers drawn; leave it to the serial kernel
-            if (lane == 0) a.fallback_list[atomicAdd(a.fallback_count, 1u)] = o;
+            // the guess keeps failing: this pixel's draws depend on the numbers drawn.  Samples up to sb stand; the
+            // rest goes to resume_kernel, serially, from the state sample sb stopped in.
+            v3 acc_color = mk(__uint_as_float(rec[2]), __uint_as_float(rec[3]), __uint_as_float(rec[4]));
+            v3 acc_em = mk(__uint_as_float(rec[5]), __uint_as_float(rec[6]), __uint_as_float(rec[7]));
+            float acc_st = __uint_as_float(rec[8]);
+            for (int s = RT_HEAVY_PROBE; s <= sb; ++s) {
+                acc_color = acc_color + mk(__shfl(so.color.x, s), __shfl(so.color.y, s), __shfl(so.color.z, s));
+                if (EMISSION) {
+                    acc_em = acc_em + mk(__shfl(so.emission.x, s), __shfl(so.emission.y, s), __shfl(so.emission.z, s));
+                    acc_st += __shfl(so.strength, s);
+                }
+            }
+            if (lane == sb) {
+                unsigned int* e = a.heavy_state + ((size_t)h * RT_HEAVY_SAMPLES + sb + 1) * 32;
+                for (int k = 0; k < 31; ++k) e[k] = slots[k * BLOCK];
+                e[31] = (unsigned int)rng.f;
+                unsigned int* w = a.heavy_rec + (size_t)h * RT_HEAVY_REC_WORDS;
+                w[2] = __float_as_uint(acc_color.x); w[3] = __float_as_uint(acc_color.y); w[4] = __float_as_uint(acc_color.z);
+                w[5] = __float_as_uint(acc_em.x); w[6] = __float_as_uint(acc_em.y); w[7] = __float_as_uint(acc_em.z);
+                w[8] = __float_as_uint(acc_st);
+                w[9] = (unsigned int)(sb + 1);
+                a.fallback_list[atomicAdd(a.fallback_count, 1u)] = h;
+            }
             return;
         }
         if (lane == sb) {
@@ -678,6 +704,51 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArg
         }
     }
     if (lane == 0) store_pixel<EMISSION>(a, (size_t)o, acc_color, acc_em, acc_st);
+}
+
+// resume_kernel: the serial pixel loop for what heavy_kernel gave up on, one lane per pixel, from the sample and the
+// generator state its record names.
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
+__global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void resume_kernel(KernelArgs a)
+{
+    extern __shared__ float4 lds[];
+    const unsigned int count = *a.fallback_count;
+    if (blockIdx.x * BLOCK >= count) return;                                 // whole workgroup: before any barrier
+    SceneLds sc;
+    float* lds_free;
+    stage_scene(a, lds, sc, lds_free);
+    __builtin_amdgcn_s_setprio(3);
+
+    const unsigned int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const unsigned int h = a.fallback_list[i];
+    const unsigned int* rec = a.heavy_rec + (size_t)h * RT_HEAVY_REC_WORDS;
+    const unsigned int o = rec[0];
+    const int next = (int)rec[9];
+    const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
+    float* dirs = lds_free + threadIdx.x;
+    primary_directions(a, dirs, x, frame_row(a, r));
+    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+
+    unsigned int* slots = (unsigned int*)(lds_free + 12 * BLOCK) + threadIdx.x;
+    typedef RngT<BLOCK> RNG;
+    RNG rng;
+    rng.init(slots, 0u);
+    rng.seeded = true;
+    const unsigned int* e = a.heavy_state + ((size_t)h * RT_HEAVY_SAMPLES + next) * 32;
+    for (int k = 0; k < 31; ++k) slots[k * BLOCK] = e[k];
+    rng.f = (int)e[31];
+
+    Counters cnt = { 0, 0, 0, 0, 0 };
+    v3 acc_color = mk(__uint_as_float(rec[2]), __uint_as_float(rec[3]), __uint_as_float(rec[4]));
+    v3 acc_em = mk(__uint_as_float(rec[5]), __uint_as_float(rec[6]), __uint_as_float(rec[7]));
+    float acc_st = __uint_as_float(rec[8]);
+    for (int s = next; s < a.samples; ++s) {
+        SampleOut so = render_sample<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, RNG, RT_LISTED_BATCH>(a, sc, rng, dirs, origin, cnt);
+        acc_color = acc_color + so.color;
+        if (EMISSION) { acc_em = acc_em + so.emission; acc_st += so.strength; }
+    }
+    store_pixel<EMISSION>(a, (size_t)o, acc_color, acc_em, acc_st);
 }
 
 // MaxRayDistance (renderer.h:204-219) per pixel, as tests/singlePixel.cpp:74-83 drives it.
@@ -870,15 +941,19 @@ bool rt_launch_heavy_fits(int n_hit, int n_lights, int n_mat)
     return listed_lds_bytes(n_hit, n_lights, n_mat) <= 160 * 1024;
 }
 
-// One wave per pixel handed over by the listed render_kernel; the grid covers the table, workgroups past the count
-// the listed kernel left in a.heavy_count leave at once.
+// heavy_kernel: one wave per pixel handed over by the listed render_kernel; the grid covers the table, workgroups past
+// the count the listed kernel left in a.heavy_count leave at once.  Then resume_kernel for what it gave up on.
 hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
 {
     const int blocks = (a.heavy_cap + BLOCK / 64 - 1) / (BLOCK / 64);
+    const int rblocks = (a.heavy_cap + BLOCK - 1) / BLOCK;
     const size_t lds = listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
-#define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N) \
-        return t.deep ? launch_with_lds(heavy_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream) \
-                      : launch_with_lds(heavy_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, stream);
+#define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N) {                                  \
+        hipError_t e = t.deep ? launch_with_lds(heavy_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream)       \
+                              : launch_with_lds(heavy_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, stream); \
+        if (e != hipSuccess) return e;                                                                                    \
+        return t.deep ? launch_with_lds(resume_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, rblocks, lds, stream)             \
+                      : launch_with_lds(resume_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, rblocks, lds, stream); }
     RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
     RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)
     RT_DISPATCH(true, false, false)  RT_DISPATCH(true, false, true)

@@ -11,6 +11,9 @@
 // pixel classes: 0 = direct, 1 + material index (RT_MAX_MATERIALS = 256)
 #define RT_MAX_KEYS 257
 #define RT_HEAVY_REC_WORDS 12
+// the listed render_kernel runs twice over the same list when long pixels are handed over (heavy_cap > 0)
+#define RT_MODE_STEADY 1   /* owns the pixels whose first samples draw equal counts and are long: hands them over */
+#define RT_MODE_REST   2   /* owns all other pixels */
 
 #define RT_STACK_SHALLOW 80
 #define RT_PEND_SHALLOW  15
@@ -44,7 +47,8 @@ struct KernelArgs {
     int heavy_cap;
     unsigned int heavy_min_work; // hand over when draws(sample 0) * (samples left) reaches this
     unsigned int* fallback_count;// pixels heavy_kernel gave up on ...
-    unsigned int* fallback_list; // ... for a serial pass of the listed render_kernel (heavy_cap entries)
+    unsigned int* fallback_list; // ... their record indices, for resume_kernel (heavy_cap entries)
+    int listed_mode;             // RT_MODE_*: which pixels of the list this launch of the listed kernel owns
 };
 
 struct LaunchTraits {
