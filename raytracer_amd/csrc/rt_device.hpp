@@ -436,6 +436,96 @@ __device__ __forceinline__ float light_intensity(const SceneLds& sc, v3 position
     return intensity;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-level candidate lists.  A pixel's four primary rays are the same for every sample (main.cpp:312 passes the same
+// u, v), and so are the shadow rays of primary hits.  A hittable whose intersect() is false for every such ray of every
+// lane of a wave stays false for all samples, and skipping a test that returns false changes nothing (the reference
+// `continue`s, hittablesList.h:25).  So a wave tests all hittables once, keeps those that returned true for some lane,
+// and runs its per-sample queries over that list, in list order (ties still go to the earlier hittable).
+// Entry j lives in lane j of one VGPR (read back with v_readlane); more than 64 entries: `full`, and the wave keeps
+// using the whole scene.  All 64 lanes must be alive while a list is built.
+struct WaveList { int items; int n; bool full; };
+
+__device__ __forceinline__ void wavelist_init(WaveList& wl) { wl.items = 0; wl.n = 0; wl.full = false; }
+
+__device__ __forceinline__ void wavelist_offer(WaveList& wl, int i, bool wanted)
+{
+    if (__ballot(wanted) != 0ull) {
+        if (wl.n < 64) { if ((int)(threadIdx.x & 63) == wl.n) wl.items = i; ++wl.n; }
+        else wl.full = true;
+    }
+}
+
+// closest_hit / closest_hit_primary over a candidate list
+template <bool HAS_NONSPHERE, bool PRIMARY>
+__device__ __forceinline__ int closest_hit_listed(const SceneLds& sc, const WaveList& wl, v3 ro, v3 rd, float& best)
+{
+    float fa = 4.0f * dot(rd, rd);
+    v3 inv = mk(0, 0, 0);
+    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    best = 3.402823466e+38f;
+    int bi = -1;
+    for (int j = 0; j < wl.n; ++j) {
+        const int i = __builtin_amdgcn_readlane(wl.items, j);
+        float d = RT_INF;
+        float t;
+        if (PRIMARY && !HAS_NONSPHERE) {
+            f32x4 p = sc.kprim[i];
+            if (sphere_hit_oc(mk(p.x, p.y, p.z), p.w, rd, fa, t)) d = t;
+        } else {
+            float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
+            if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, t)) d = t;
+        }
+        if (!(d >= best)) { best = d; bi = i; }
+    }
+    return bi;
+}
+
+template <bool HAS_NONSPHERE, bool LIMITED>
+__device__ __forceinline__ bool any_hit_listed(const SceneLds& sc, const WaveList& wl, v3 ro, v3 rd, float limit)
+{
+    float fa = 4.0f * dot(rd, rd);
+    v3 inv = mk(0, 0, 0);
+    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    for (int j = 0; j < wl.n; ++j) {
+        const int i = __builtin_amdgcn_readlane(wl.items, j);
+        float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
+        if (occluder_hit<HAS_NONSPHERE, false, LIMITED>(r0, r1, ro, rd, fa, inv, limit)) return true;
+    }
+    return false;
+}
+
+// direction towards light i from `position` (directionalLight.h:9,17; point light: repo-defined), its type and distance
+__device__ __forceinline__ v3 light_direction(const SceneLds& sc, int i, v3 position, int& type, float& dist)
+{
+    float4 L = sc.ulight(i);
+    type = __builtin_amdgcn_readfirstlane(__float_as_int(L.w));
+    dist = 0.0f;
+    if (type == L_DIR) return mk(L.x, L.y, L.z);
+    v3 dv = mk(L.x, L.y, L.z) - position;
+    dist = sqrtf(dot(dv, dv));
+    return normalize(dv);
+}
+
+// light_intensity<.., PRUNE = true> with the occlusion queries over a candidate list
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ float light_intensity_listed(const SceneLds& sc, const WaveList& wl, v3 position, v3 normal)
+{
+    float intensity = 0.085f;
+    for (int i = 0; i < sc.n_lights; ++i) {
+        int type; float dist;
+        v3 l = light_direction(sc, i, position, type, dist);
+        float d = dot(normal, l);
+        float intens = d > 0 ? d : 0;
+        if (intens > intensity) {
+            bool occluded = (type == L_DIR) ? any_hit_listed<HAS_NONSPHERE, false>(sc, wl, position, l, 0.0f)
+                                            : any_hit_listed<HAS_NONSPHERE, true>(sc, wl, position, l, dist);
+            if (!occluded) intensity = intens;
+        }
+    }
+    return intensity;
+}
+
 // RANDOM_UNIT_EMISPHERE (core.h:24-35): three draws in x, y, z order, normalise, flip into the normal's hemisphere
 template <bool COUNT, class RNG>
 __device__ __forceinline__ v3 random_unit_hemisphere(RNG& rng, v3 normal, Counters& cnt)

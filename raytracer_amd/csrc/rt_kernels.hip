@@ -25,6 +25,9 @@ constexpr int BLOCK = 256;
 #ifndef RT_LISTED_BATCH
 #define RT_LISTED_BATCH 4
 #endif
+#ifndef RT_DIRECT_CULL
+#define RT_DIRECT_CULL 1
+#endif
 #ifndef RT_DIRECT_BATCH
 #define RT_DIRECT_BATCH 4
 #endif
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(const unsigned short* __
 // direct_kernel: the per-pixel driver for pixels whose primary rays never bounce.  TraceRay then is: closest hit ->
 // sky (renderer.h:40-50) or one shading (renderer.h:55-66) with multiplier 1 and maxDepth = depth = 1
 // (renderer.h:128-132), so color / vec3(maxDepth) is color / 1 and no random number is drawn.
-template <bool EMISSION, bool HAS_NONSPHERE>
+template <bool EMISSION, bool HAS_NONSPHERE, bool CULL = (RT_DIRECT_CULL != 0)>
 __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
@@ -515,14 +518,71 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
     stage_scene(a, lds, sc, lds_free);
 
     const PixelId p = tiled_pixel(a);
-    if (!p.active) return;
     const size_t o = (size_t)p.x + (size_t)p.r * a.width;
-    if (a.keys && a.keys[o] != 0) return;              // render_kernel has this pixel
+    // lanes off the frame, and lanes whose pixel render_kernel has, stay until the candidate lists are built
+    const bool mine = p.active && !(a.keys && a.keys[o] != 0);
 
     float* dirs = lds_free + threadIdx.x;
     primary_directions(a, dirs, p.x, p.y);
     const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
     Counters none = { 0, 0, 0, 0, 0 };
+
+    // Candidate lists of this wave (rt_device.hpp "wave-level candidate lists"): hittables some primary ray of the wave
+    // hits, and hittables that occlude some light from some primary hit point.  One pass over the scene, then every
+    // sample's queries run over the lists.
+    WaveList prim, occl;
+    wavelist_init(prim); wavelist_init(occl);
+    if (CULL) {
+        for (int i = 0; i < sc.n_hit; ++i) {
+            float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
+            bool any = false;
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+                float fa = 4.0f * dot(rd, rd);
+                v3 inv = mk(0, 0, 0);
+                if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                float t;
+                if (!HAS_NONSPHERE) {
+                    // the same operands as closest_hit_primary (camera-relative terms)
+                    f32x4 q = sc.kprim[i];
+                    any = any || sphere_hit_oc(mk(q.x, q.y, q.z), q.w, rd, fa, t);
+                } else {
+                    any = any || hittable_hit<HAS_NONSPHERE>(r0, r1, origin, rd, fa, inv, t);
+                }
+            }
+            wavelist_offer(prim, i, any && mine);
+        }
+        if (!prim.full) {
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+                float dist;
+                int bi = closest_hit_listed<HAS_NONSPHERE, true>(sc, prim, origin, rd, dist);
+                const bool hit = mine && bi >= 0;
+                v3 pos = mk(0, 0, 0);
+                if (hit) { Hit h = hit_record(sc, bi, origin, rd, dist); pos = h.position + h.normal * 0.005f; }
+                for (int j = 0; j < sc.n_lights; ++j) {
+                    int type; float ldist;
+                    v3 l = light_direction(sc, j, pos, type, ldist);
+                    float fa = 4.0f * dot(l, l);
+                    v3 inv = mk(0, 0, 0);
+                    if (HAS_NONSPHERE) inv = mk(1.0f / l.x, 1.0f / l.y, 1.0f / l.z);
+                    for (int i = 0; i < sc.n_hit; ++i) {
+                        float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
+                        bool o = hit && ((type == L_DIR) ? occluder_hit<HAS_NONSPHERE, false, false>(r0, r1, pos, l, fa, inv, 0.0f)
+                                                         : occluder_hit<HAS_NONSPHERE, false, true>(r0, r1, pos, l, fa, inv, ldist));
+                        // one list for all rays and lights: offer only what is not on it yet
+                        bool known = false;
+                        for (int e = 0; e < occl.n; ++e) known = known || __builtin_amdgcn_readlane(occl.items, e) == i;
+                        if (!known) wavelist_offer(occl, i, o);
+                    }
+                }
+            }
+        }
+    }
+    const bool culled = CULL && !prim.full && !occl.full;
+    if (!mine) return;
 
     v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0);
     float acc_st = 0.0f;
@@ -533,7 +593,8 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
         for (int k = 0; k < 4; ++k) {                                        // renderer.h:167-195
             v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
             float dist;
-            int bi = primary_closest<HAS_NONSPHERE, RT_DIRECT_BATCH>(sc, origin, rd, dist);
+            int bi = culled ? closest_hit_listed<HAS_NONSPHERE, true>(sc, prim, origin, rd, dist)
+                            : primary_closest<HAS_NONSPHERE, RT_DIRECT_BATCH>(sc, origin, rd, dist);
             v3 color, em = mk(0, 0, 0);
             float st = 0.0f;
             if (bi < 0) {                                                    // renderer.h:47-49
@@ -543,7 +604,8 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
             } else {
                 Hit h = hit_record(sc, bi, origin, rd, dist);
                 v3 offPosition = h.position + h.normal * 0.005f;             // renderer.h:55
-                float intensity = light_intensity<HAS_NONSPHERE, false, true, RT_DIRECT_BATCH>(sc, offPosition, h.normal, none);
+                float intensity = culled ? light_intensity_listed<HAS_NONSPHERE>(sc, occl, offPosition, h.normal)
+                                         : light_intensity<HAS_NONSPHERE, false, true, RT_DIRECT_BATCH>(sc, offPosition, h.normal, none);
                 const float* m = sc.mats + 10 * h.material;
                 color = (mk(m[0], m[1], m[2]) * intensity) * 1.0f;           // renderer.h:64
                 if (EMISSION) { em = mk(m[6], m[7], m[8]); st = m[9]; }
