@@ -32,7 +32,9 @@ BAND_ROWS = 16
 
 
 def algorithmic_flops(cnt, scene, n_pixels, samples):
-    """SURVEY.md section 8(d) per-op table applied to the tallies of the kernel's counting build (executed work):
+    """SURVEY.md section 8(d) per-op table applied to the frame's query tallies as the reference algorithm issues them
+    (the device counting build, equal to the oracle's tallies) -- the algorithmic work of the frame, not what the
+    production kernels execute: they skip tests that are known to fail.
     ray generation 71 + per-ray accumulate 10; primitive test 30 sphere / 14 plane / 28 cube (type-weighted by the
     scene's mix, exact for single-type scenes); per shaded hit: epilogue 19 + shade 17 + 6 per light; sky 15;
     bounce 76 (the cheaper of reflection 76 / refraction 95, the tallies do not split them); per-sample clamp/add 19;
@@ -151,10 +153,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # exact tallies of this frame (untimed): counting build with the production kernel's shadow-query pruning
-    from raytracer_amd import _abi
+    # exact tallies of this frame (untimed): the counting build issues every query the reference issues
     pc = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank)
-    cnt = rt.render_rows(cam, pc, block, count=True, executed=True)
+    cnt = rt.render_rows(cam, pc, block, count=True)
     keys = ("primary", "closest", "shadow", "tests", "rand_draws", "shaded")
     tv = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device=dev)
     local_flops = algorithmic_flops(cnt, scene, W * p.rows, samples)
@@ -180,20 +181,24 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp": samples, "max_depth": depth,
                        "seed_base": seed, "parallelism": "cyclic %d-row bands over %d GPU(s), RCCL gather to rank 0" % (BAND_ROWS, world)},
-            "rays": {"primary": tot["primary"], "secondary": tot["closest"] - tot["primary"], "shadow_executed": tot["shadow"],
-                     "primitive_tests_executed": tot["tests"], "rng_draws": tot["rand_draws"]},
+            "rays": {"primary": tot["primary"], "secondary": tot["closest"] - tot["primary"], "shadow": tot["shadow"],
+                     "primitive_tests": tot["tests"], "rng_draws": tot["rand_draws"],
+                     "note": "queries of the reference algorithm for this frame (device tally == oracle tally)"},
             "kernel_ms": round(kms, 3), "device_ms_rank0": round(float(np.mean(device_ms)), 3),
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                         "note": "algorithmic FP32 flops (SURVEY 8d table x executed tallies) / kernel time from HIP events; "
-                                 "no FMA contraction (bit parity), so 0.5 is the ceiling of this definition; "
-                                 "VALU issue utilisation from PMC counters is in profiles/"},
+                         "note": "algorithmic FP32 flops of the frame (SURVEY 8d table x the reference algorithm's query "
+                                 "tallies) / duration of the frame's render kernels (direct, listed, heavy: they overlap) "
+                                 "from HIP events. The kernels execute fewer flops than that: per-wave candidate lists "
+                                 "and shadow-query pruning skip tests known to fail, so frac can pass the 0.5 that "
+                                 "un-fused FP32 code could reach by brute force. Executed VALU issue utilisation per "
+                                 "kernel (PMC counters) is in profiles/"},
         }
         if not args.no_cpu_baseline and world == 1:
             def count_rays(step):
                 n = (H + step - 1) // step
                 ps = rt.params(W, H, samples, depth, seed, row0=0, rows=n, band_rows=1, band_stride=step)
-                return rt.render_rows(cam, ps, block[:n], count=True, executed=True)["closest"]
+                return rt.render_rows(cam, ps, block[:n], count=True)["closest"]
             line["cpu_baseline"] = cpu_baseline(scene, W, H, samples, depth, count_rays)
         print(json.dumps(line), flush=True)
     rt.close()

@@ -10,10 +10,13 @@
 #include <new>
 #include <vector>
 
-// sample-parallel pixels: table capacity (8 KiB of generator states per pixel) and the hand-over threshold in
+// sample-parallel pixels: table capacity (pixels, bytes) and the hand-over threshold in
 // draws(sample 0) * (samples - 1); a pixel below it is quicker left to its own lane
 #ifndef RT_HEAVY_CAP
-#define RT_HEAVY_CAP 16384
+#define RT_HEAVY_CAP 262144
+#endif
+#ifndef RT_HEAVY_TABLE_BYTES
+#define RT_HEAVY_TABLE_BYTES ((size_t)512 << 20)
 #endif
 #ifndef RT_HEAVY_MIN_WORK
 #define RT_HEAVY_MIN_WORK 12000u
@@ -411,16 +414,24 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                 // one lane per sample, by the heavy kernel behind it (DESIGN.md "sample-parallel pixels").
                 const bool force = (p->flags & RT_FLAG_FORCE_SAMPLE_PARALLEL) != 0;
                 if (p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
-                    const size_t cap = n_listed < RT_HEAVY_CAP ? n_listed : RT_HEAVY_CAP;
-                    rc = grow(ctx, &ctx->d_heavy, &ctx->heavy_bytes, 16 + cap * 4 * (64 * 32 + RT_HEAVY_REC_WORDS + 1));
+                    // table: one generator state (128 B) per remaining sample of every handed-over pixel
+                    const size_t entries = (size_t)(p->samples - RT_HEAVY_PROBE);
+                    size_t cap = RT_HEAVY_TABLE_BYTES / (entries * 128);
+                    if (cap > RT_HEAVY_CAP) cap = RT_HEAVY_CAP;
+                    if (cap > n_listed) cap = n_listed;
+                    rc = grow(ctx, &ctx->d_heavy, &ctx->heavy_bytes, 16 + cap * 4 * (entries * 32 + RT_HEAVY_REC_WORDS + 1));
                     if (rc) return rc;
                     g2.heavy_count = (unsigned int*)ctx->d_heavy;
                     g2.fallback_count = g2.heavy_count + 1;
                     g2.heavy_state = g2.heavy_count + 4;
-                    g2.heavy_rec = g2.heavy_state + cap * (64 * 32);
+                    g2.heavy_rec = g2.heavy_state + cap * (entries * 32);
                     g2.fallback_list = g2.heavy_rec + cap * RT_HEAVY_REC_WORDS;
                     g2.heavy_cap = (int)cap;
-                    g2.heavy_min_work = force ? 0u : RT_HEAVY_MIN_WORK;
+                    // the threshold is tuned on DEFAULT-4 (4 hittables, 1 light: 8 primitive tests per query pair);
+                    // a bounce costs in proportion to hittables x (1 + lights)
+                    const double per_bounce = (double)ctx->n_hit * (1.0 + ctx->n_lights) / 8.0;
+                    double min_work = RT_HEAVY_MIN_WORK / (per_bounce > 1.0 ? per_bounce : 1.0);
+                    g2.heavy_min_work = force ? 0u : (unsigned int)(min_work < 1.0 ? 1.0 : min_work);
                     HIP_TRY(ctx, hipMemsetAsync(g2.heavy_count, 0, 16, ctx->stream2));
                 }
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_list, 0));

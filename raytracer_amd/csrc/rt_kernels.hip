@@ -37,10 +37,6 @@ constexpr int BLOCK = 256;
 // sample-parallel pixels: at most this many samples (one wave, one lane per sample)
 #define RT_HEAVY_SAMPLES 64
 // re-guesses per pixel before it is sent back to the serial kernel
-// samples the serial kernel does first: they must all draw the same count for the pixel to be handed over
-#ifndef RT_HEAVY_PROBE
-#define RT_HEAVY_PROBE 4
-#endif
 #ifndef RT_HEAVY_ROUNDS
 #define RT_HEAVY_ROUNDS 4
 #endif
@@ -353,8 +349,8 @@ __device__ __forceinline__ void store_pixel(const KernelArgs& a, size_t o, v3 ac
 
 // Hands a long pixel over to heavy_kernel (DESIGN.md "sample-parallel pixels").  Called after the first
 // RT_HEAVY_PROBE samples, which drew d0 numbers each: the generator state at the start of sample s is recorded for
-// every later s, on the guess that every sample draws d0 numbers; heavy_kernel checks the guess.  Table entry: 31 words + front slot, RT_HEAVY_SAMPLES
-// entries per pixel; record: pixel, d0, the sums over the samples done.  Returns false when the table is full (the
+// every later s, on the guess that every sample draws d0 numbers; heavy_kernel checks the guess.  Table entry: 31 words + front slot, one
+// entry per remaining sample; record: pixel, d0, the sums over the samples done.  Returns false when the table is full (the
 // caller then carries on itself).
 template <class RNG>
 __device__ __forceinline__ bool heavy_handover(const KernelArgs& a, RNG& rng, unsigned int pixel, unsigned int d0,
@@ -367,9 +363,9 @@ __device__ __forceinline__ bool heavy_handover(const KernelArgs& a, RNG& rng, un
     rec[2] = __float_as_uint(acc_color.x); rec[3] = __float_as_uint(acc_color.y); rec[4] = __float_as_uint(acc_color.z);
     rec[5] = __float_as_uint(acc_em.x); rec[6] = __float_as_uint(acc_em.y); rec[7] = __float_as_uint(acc_em.z);
     rec[8] = __float_as_uint(acc_st);
-    unsigned int* tab = a.heavy_state + (size_t)h * (RT_HEAVY_SAMPLES * 32);
+    unsigned int* tab = a.heavy_state + (size_t)h * (a.samples - RT_HEAVY_PROBE) * 32;
     for (int s = RT_HEAVY_PROBE; s < a.samples; ++s) {
-        unsigned int* e = tab + s * 32;
+        unsigned int* e = tab + (s - RT_HEAVY_PROBE) * 32;
         for (int k = 0; k < 31; ++k) e[k] = rng.r[k * RNG::stride];
         e[31] = (unsigned int)rng.f;
         if (s + 1 < a.samples)
@@ -693,7 +689,7 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArg
     rng.init(slots, 0u);
     rng.seeded = true;
     if (active) {
-        const unsigned int* e = a.heavy_state + ((size_t)h * RT_HEAVY_SAMPLES + lane) * 32;
+        const unsigned int* e = a.heavy_state + ((size_t)h * (a.samples - RT_HEAVY_PROBE) + (lane - RT_HEAVY_PROBE)) * 32;
         for (int k = 0; k < 31; ++k) slots[k * BLOCK] = e[k];
         rng.f = (int)e[31];
     }
@@ -726,7 +722,7 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArg
                 }
             }
             if (lane == sb) {
-                unsigned int* e = a.heavy_state + ((size_t)h * RT_HEAVY_SAMPLES + sb + 1) * 32;
+                unsigned int* e = a.heavy_state + ((size_t)h * (a.samples - RT_HEAVY_PROBE) + (sb + 1 - RT_HEAVY_PROBE)) * 32;
                 for (int k = 0; k < 31; ++k) e[k] = slots[k * BLOCK];
                 e[31] = (unsigned int)rng.f;
                 unsigned int* w = a.heavy_rec + (size_t)h * RT_HEAVY_REC_WORDS;
@@ -797,7 +793,7 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void resume_kernel(KernelAr
     RNG rng;
     rng.init(slots, 0u);
     rng.seeded = true;
-    const unsigned int* e = a.heavy_state + ((size_t)h * RT_HEAVY_SAMPLES + next) * 32;
+    const unsigned int* e = a.heavy_state + ((size_t)h * (a.samples - RT_HEAVY_PROBE) + (next - RT_HEAVY_PROBE)) * 32;
     for (int k = 0; k < 31; ++k) slots[k * BLOCK] = e[k];
     rng.f = (int)e[31];
 
