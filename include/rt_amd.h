@@ -92,13 +92,14 @@ typedef struct {
     int32_t flags;               /* RT_FLAG_* */
 } rt_params;
 
-#define RT_FLAG_COUNT_LIKE_REFERENCE 1  /* tally, issuing every shadow query the reference would issue (slower)  */
-#define RT_FLAG_SINGLE_KERNEL         4  /* A/B: one general kernel over every pixel instead of the direct + general
-                                           kernel pair (DESIGN.md "execution model")                              */
+#define RT_FLAG_COUNT_LIKE_REFERENCE  1  /* tally, issuing every query the reference would issue (one general kernel
+                                           over every pixel; slower)                                              */
+#define RT_FLAG_COUNT_EXECUTED        2  /* tally the general kernel with its shadow-query pruning (queries that cannot
+                                           change the pixel are skipped)                      */
+#define RT_FLAG_SINGLE_KERNEL         4  /* A/B: one general kernel over every pixel instead of the direct + listed +
+                                           heavy kernels (DESIGN.md "execution model")                            */
 #define RT_FLAG_FORCE_SAMPLE_PARALLEL 8  /* test hook: every bounce pixel takes the sample-parallel route that only
-                                           long pixels take otherwise (DESIGN.md "sample-parallel pixels")          */
-#define RT_FLAG_COUNT_EXECUTED       2  /* tally the production kernel's own work (shadow queries that cannot
-                                           change the pixel are skipped)                          */
+                                           long pixels take otherwise (DESIGN.md "execution model", 3)            */
 
 /* Query tallies with the reference's meaning: primary = W*rows*samples*4; closest = TraceRay closest-hit queries
  * (src/renderer.h:40); shadow = hasIntersect / point-light occlusion queries (directionalLight.h:13); tests =
@@ -139,8 +140,8 @@ int rt_deinterleave_bands(rt_ctx* ctx, const void* gathered, void* frame_out, in
                           int32_t bytes_per_pixel, int32_t band_rows, int32_t nranks, int32_t rows_per_rank);
 
 /* Durations in milliseconds of the last rt_render_rows, from HIP events on the context's stream: from the launch of
- * the direct kernel to the end of both render kernels, and all device work of the call (pixel classification
- * included). */
+ * the direct kernel to the end of all render kernels of the call (direct, listed, heavy, resume: they overlap), and
+ * all device work of the call (pixel classification included). */
 float rt_last_kernel_ms(const rt_ctx* ctx);
 float rt_last_device_ms(const rt_ctx* ctx);
 /* hipError_t of the last failing HIP call (0 if none). */
