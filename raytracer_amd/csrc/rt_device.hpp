@@ -10,7 +10,6 @@
 #ifndef RT_UNROLL
 #define RT_UNROLL 1
 #endif
-#define RT_INF __builtin_huge_valf()
 
 namespace rt {
 
@@ -272,7 +271,8 @@ __device__ __forceinline__ Hit hit_record(const SceneLds& sc, int idx, v3 ro, v3
 }
 
 // HittablesList::intersect (hittablesList.h:17-37): brute force, strict '<' so the earlier hittable wins ties;
-// a candidate replaces the best unless `dist >= best` (NaN distances therefore replace, as in the reference).
+// a hit replaces the best unless `dist >= best` (NaN distances therefore replace, and once the best is a NaN every
+// later hit replaces it, as in the reference; a miss never does).
 // BATCH > 1 reads the records of BATCH hittables before testing the first: one memory round trip per BATCH tests,
 // for kernels whose waves wait on latency rather than on issue slots.
 template <bool HAS_NONSPHERE, bool COUNT, int BATCH = 1>
@@ -292,10 +292,8 @@ __device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, flo
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
                 if (COUNT) ++cnt.tests;
-                float d = RT_INF;
                 float t;
-                if (hittable_hit<HAS_NONSPHERE>(r[2 * j], r[2 * j + 1], ro, rd, fa, inv, t)) d = t;
-                if (!(d >= best)) { best = d; bi = i + j; }
+                if (hittable_hit<HAS_NONSPHERE>(r[2 * j], r[2 * j + 1], ro, rd, fa, inv, t) && !(t >= best)) { best = t; bi = i + j; }
             }
         }
     }
@@ -303,10 +301,8 @@ __device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, flo
     for (; i < sc.n_hit; ++i) {
         float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
         if (COUNT) ++cnt.tests;
-        float d = RT_INF;
         float t;
-        if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, t)) d = t;
-        if (!(d >= best)) { best = d; bi = i; }
+        if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, t) && !(t >= best)) { best = t; bi = i; }
     }
     return bi;
 }
@@ -328,10 +324,8 @@ __device__ __forceinline__ int closest_hit_primary(const SceneLds& sc, v3 rd, fl
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
                 if (COUNT) ++cnt.tests;
-                float d = RT_INF;
                 float t;
-                if (sphere_hit_oc(mk(p[j].x, p[j].y, p[j].z), p[j].w, rd, fa, t)) d = t;
-                if (!(d >= best)) { best = d; bi = i + j; }
+                if (sphere_hit_oc(mk(p[j].x, p[j].y, p[j].z), p[j].w, rd, fa, t) && !(t >= best)) { best = t; bi = i + j; }
             }
         }
     }
@@ -339,11 +333,8 @@ __device__ __forceinline__ int closest_hit_primary(const SceneLds& sc, v3 rd, fl
     for (; i < sc.n_hit; ++i) {
         f32x4 p = sc.kprim[i];
         if (COUNT) ++cnt.tests;
-        // a miss yields +inf, which `!(d >= best)` rejects exactly like the reference's `continue`
-        float d = RT_INF;
         float t;
-        if (sphere_hit_oc(mk(p.x, p.y, p.z), p.w, rd, fa, t)) d = t;
-        if (!(d >= best)) { best = d; bi = i; }
+        if (sphere_hit_oc(mk(p.x, p.y, p.z), p.w, rd, fa, t) && !(t >= best)) { best = t; bi = i; }
     }
     return bi;
 }
@@ -467,16 +458,16 @@ __device__ __forceinline__ int closest_hit_listed(const SceneLds& sc, const Wave
     int bi = -1;
     for (int j = 0; j < wl.n; ++j) {
         const int i = __builtin_amdgcn_readlane(wl.items, j);
-        float d = RT_INF;
         float t;
+        bool hit;
         if (PRIMARY && !HAS_NONSPHERE) {
             f32x4 p = sc.kprim[i];
-            if (sphere_hit_oc(mk(p.x, p.y, p.z), p.w, rd, fa, t)) d = t;
+            hit = sphere_hit_oc(mk(p.x, p.y, p.z), p.w, rd, fa, t);
         } else {
             float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
-            if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, t)) d = t;
+            hit = hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, t);
         }
-        if (!(d >= best)) { best = d; bi = i; }
+        if (hit && !(t >= best)) { best = t; bi = i; }
     }
     return bi;
 }

@@ -273,7 +273,32 @@ def degenerate_scene() -> Scene:
     return s
 
 
+def nan_scene() -> Scene:
+    """Not-a-number rules of the closest-hit loop (hittablesList.h:25: `dist >= best` is false for a NaN on either
+    side): a sphere with a NaN radius 'hits' every ray at a NaN distance and replaces the best so far; after it only
+    real hits replace, misses do not; a second NaN sphere further down the list takes over from whatever came before."""
+    s = Scene(name="nan")
+    _default_materials(s)
+    nan = float("nan")
+    s.sphere((0.0, -1000.0, -4.0), 1000.0, 0)
+    s.sphere((0.0, 1.0, -4.0), nan, 1)              # NaN distance for every ray
+    s.sphere((-3.0, 1.0, -4.0), 1.0, 2)             # most rays miss it: a miss must not replace the NaN best
+    s.sphere((3.0, 1.0, -4.0), 1.0, 3)
+    s.cube((-0.5, 0.0, -1.0), (1.0, 1.0, 1.0), 2)
+    s.dirlight((-0.25, -0.75, 0.45))
+    return s
+
+
+def nan_tail_scene() -> Scene:
+    """nan_scene with another NaN sphere at the end of the list."""
+    s = nan_scene()
+    s.name = "nan_tail"
+    s.sphere((1.0, 2.0, -2.0), float("nan"), 0)
+    return s
+
+
 BUILTIN = {
     "default4": default4, "random10": random10, "many_objects": many_objects, "glass_mirror": glass_mirror,
     "plane": plane_scene, "cube": cube_scene, "pointlights": point_light_scene, "degenerate": degenerate_scene,
+    "nan": nan_scene, "nan_tail": nan_tail_scene,
 }

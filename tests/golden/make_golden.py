@@ -35,6 +35,8 @@ CASES = [
     ("pointlights_128x64_s2_d6_seed5", scenes.point_light_scene, 128, 64, 2, 6, 5),
     ("degenerate_128x64_s4_d10_seed0", scenes.degenerate_scene, 128, 64, 4, 10, 0),
     ("degenerate_100x36_s1_d0_seed3", scenes.degenerate_scene, 100, 36, 1, 0, 3),
+    ("nan_96x64_s2_d4_seed1", scenes.nan_scene, 96, 64, 2, 4, 1),
+    ("nan_tail_96x64_s2_d4_seed1", scenes.nan_tail_scene, 96, 64, 2, 4, 1),
 ]
 
 

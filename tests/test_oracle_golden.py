@@ -93,7 +93,8 @@ def test_scene_text_round_trip():
     for name, builder in scenes.BUILTIN.items():
         sc = builder()
         again = scenes.Scene.from_text(sc.to_text())
-        assert again.materials == sc.materials and again.hittables == sc.hittables and again.lights == sc.lights, name
+        # repr(): the NaN radius of the nan scenes compares unequal to itself
+        assert repr((again.materials, again.hittables, again.lights)) == repr((sc.materials, sc.hittables, sc.lights)), name
     with pytest.raises(ValueError):
         scenes.Scene.from_text("sphere 1 2 3\n")
     with pytest.raises(ValueError):
