@@ -15,6 +15,10 @@
 #ifndef RT_HEAVY_CAP
 #define RT_HEAVY_CAP 262144
 #endif
+// scenes with at least this many hittables render their bounce pixels one wave per pixel (coop_kernel)
+#ifndef RT_COOP_MIN_HIT
+#define RT_COOP_MIN_HIT 256
+#endif
 #ifndef RT_HEAVY_TABLE_BYTES
 #define RT_HEAVY_TABLE_BYTES ((size_t)512 << 20)
 #endif
@@ -413,7 +417,10 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                 // Long pixels leave the listed kernel after their first sample and are finished one wave per pixel,
                 // one lane per sample, by the heavy kernel behind it (DESIGN.md "sample-parallel pixels").
                 const bool force = (p->flags & RT_FLAG_FORCE_SAMPLE_PARALLEL) != 0;
-                if (p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
+                // Large scenes: one wave per listed pixel, the lanes share every scan of the scene (coop_kernel)
+                const bool coop = ctx->n_hit >= RT_COOP_MIN_HIT && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)
+                                  && !force;
+                if (!coop && p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
                     // table: one generator state (128 B) per remaining sample of every handed-over pixel
                     const size_t entries = (size_t)(p->samples - RT_HEAVY_PROBE);
                     size_t cap = RT_HEAVY_TABLE_BYTES / (entries * 128);
@@ -435,7 +442,9 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                     HIP_TRY(ctx, hipMemsetAsync(g2.heavy_count, 0, 16, ctx->stream2));
                 }
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_list, 0));
-                if (g2.heavy_cap > 0) {
+                if (coop) {
+                    HIP_TRY(ctx, rt_launch_coop(g2, tg, ctx->stream2));
+                } else if (g2.heavy_cap > 0) {
                     // the steady long pixels: first samples, hand-over, heavy kernel, resume kernel ...
                     g2.listed_mode = RT_MODE_STEADY;
                     HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream2));

@@ -224,12 +224,12 @@ __device__ __forceinline__ bool cube_hit(float4 r0, float4 r1, v3 ro, v3 inv, fl
 __device__ __forceinline__ int rec_type(float4 r1) { return __float_as_int(r1.w) & 3; }
 __device__ __forceinline__ int rec_material(float4 r1) { return __float_as_int(r1.w) >> 2; }
 
-template <bool HAS_NONSPHERE>
+template <bool HAS_NONSPHERE, bool UNIFORM = true>
 __device__ __forceinline__ bool hittable_hit(float4 r0, float4 r1, v3 ro, v3 rd, float fa, v3 inv, float& dist)
 {
     if (HAS_NONSPHERE) {
-        // the record index is wave-uniform, so the type is too: make the branch scalar
-        int type = __builtin_amdgcn_readfirstlane(rec_type(r1));
+        // UNIFORM: the record index is wave-uniform, so the type is too: make the branch scalar
+        int type = UNIFORM ? __builtin_amdgcn_readfirstlane(rec_type(r1)) : rec_type(r1);
         if (type == T_PLANE) return plane_hit(r0, r1, ro, rd, dist);
         if (type == T_CUBE)  return cube_hit(r0, r1, ro, inv, dist);
     }
@@ -270,6 +270,68 @@ __device__ __forceinline__ Hit hit_record(const SceneLds& sc, int idx, v3 ro, v3
     return h;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cooperative scans (BATCH == RT_COOP): all 64 lanes of the wave hold the *same* ray (one wave renders one pixel, every
+// lane runs the same path code on the same values) and share the scan of the scene: lane l tests hittables l, l + 64,
+// ... from the LDS copy, then the wave combines.  Without NaN distances the sequential rule (a hit replaces unless
+// `dist >= best`, best starting at FLT_MAX) picks the smallest distance below FLT_MAX and, among equals, the lowest
+// index; that is what each lane computes over its indices and what the butterfly computes over lanes.  A NaN distance
+// anywhere makes the order of replacements matter (hittablesList.h:25): the wave then repeats the query sequentially.
+#define RT_COOP (-1)
+
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ int closest_hit_seq(const SceneLds& sc, v3 ro, v3 rd, float& best);
+
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd, float& best)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    float fa = 4.0f * dot(rd, rd);
+    v3 inv = mk(0, 0, 0);
+    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    best = 3.402823466e+38f;
+    int bi = -1;
+    bool nan_seen = false;
+    for (int i = lane; i < sc.n_hit; i += 64) {
+        float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+        float t;
+        if (hittable_hit<HAS_NONSPHERE, false>(r0, r1, ro, rd, fa, inv, t)) {
+            nan_seen = nan_seen || (t != t);
+            if (!(t >= best)) { best = t; bi = i; }
+        }
+    }
+    if (__ballot(nan_seen) != 0ull) return closest_hit_seq<HAS_NONSPHERE>(sc, ro, rd, best);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        float ot = __shfl_xor(best, m);
+        int oi = __shfl_xor(bi, m);
+        // no-hit lanes carry (FLT_MAX, -1): any hit is below FLT_MAX, two hits at the same distance go to the lower index
+        bool take = ot < best || (ot == best && oi >= 0 && (bi < 0 || oi < bi));
+        if (take) { best = ot; bi = oi; }
+    }
+    return bi;
+}
+
+template <bool HAS_NONSPHERE, bool LIMITED>
+__device__ __forceinline__ bool any_hit_coop(const SceneLds& sc, v3 ro, v3 rd, float limit)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    float fa = 4.0f * dot(rd, rd);
+    v3 inv = mk(0, 0, 0);
+    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    // 64 hittables per round; the first round with an occluder ends the query (any order gives the same boolean)
+    for (int base = 0; base < sc.n_hit; base += 64) {
+        const int i = base + lane;
+        bool o = false;
+        if (i < sc.n_hit) {
+            float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+            o = occluder_hit<HAS_NONSPHERE, false, LIMITED, false>(r0, r1, ro, rd, fa, inv, limit);
+        }
+        if (__ballot(o) != 0ull) return true;
+    }
+    return false;
+}
+
 // HittablesList::intersect (hittablesList.h:17-37): brute force, strict '<' so the earlier hittable wins ties;
 // a hit replaces the best unless `dist >= best` (NaN distances therefore replace, and once the best is a NaN every
 // later hit replaces it, as in the reference; a miss never does).
@@ -278,6 +340,7 @@ __device__ __forceinline__ Hit hit_record(const SceneLds& sc, int idx, v3 ro, v3
 template <bool HAS_NONSPHERE, bool COUNT, int BATCH = 1>
 __device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, float& best, Counters& cnt)
 {
+    if (BATCH == RT_COOP) return closest_hit_coop<HAS_NONSPHERE>(sc, ro, rd, best);
     float fa = 4.0f * dot(rd, rd);
     v3 inv = mk(0, 0, 0);
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
@@ -286,7 +349,7 @@ __device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, flo
     int i = 0;
     if (BATCH > 1) {
         for (; i + BATCH <= sc.n_hit; i += BATCH) {
-            float4 r[2 * BATCH];
+            float4 r[2 * (BATCH > 1 ? BATCH : 1)];
 #pragma unroll
             for (int j = 0; j < 2 * BATCH; ++j) r[j] = sc.urec(2 * i + j);
 #pragma unroll
@@ -307,6 +370,13 @@ __device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, flo
     return bi;
 }
 
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ int closest_hit_seq(const SceneLds& sc, v3 ro, v3 rd, float& best)
+{
+    Counters none = { 0, 0, 0, 0, 0 };
+    return closest_hit<HAS_NONSPHERE, false, 1>(sc, ro, rd, best, none);
+}
+
 // The same query for a primary ray of a sphere-only scene: all primary rays start at the camera, so
 // (origin - centre, dot(..) - r*r) come precomputed per sphere (rt_abi.cpp, the same float operations).
 template <bool COUNT, int BATCH = 1>
@@ -318,7 +388,7 @@ __device__ __forceinline__ int closest_hit_primary(const SceneLds& sc, v3 rd, fl
     int i = 0;
     if (BATCH > 1) {
         for (; i + BATCH <= sc.n_hit; i += BATCH) {
-            f32x4 p[BATCH];
+            f32x4 p[BATCH > 1 ? BATCH : 1];
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) p[j] = sc.kprim[i + j];
 #pragma unroll
@@ -341,30 +411,31 @@ __device__ __forceinline__ int closest_hit_primary(const SceneLds& sc, v3 rd, fl
 
 // HittablesList::hasIntersect (hittablesList.h:39-50): first hittable whose intersect() is true, no distance bound.
 // With `limit`: the point-light occlusion test "some hittable is hit strictly closer than the light".
-template <bool HAS_NONSPHERE, bool COUNT, bool LIMITED>
+template <bool HAS_NONSPHERE, bool COUNT, bool LIMITED, bool UNIFORM = true>
 __device__ __forceinline__ bool occluder_hit(float4 r0, float4 r1, v3 ro, v3 rd, float fa, v3 inv, float limit)
 {
     if (!LIMITED) {
         // directional light: only the boolean matters
         bool is_sphere = true;
-        if (HAS_NONSPHERE) is_sphere = __builtin_amdgcn_readfirstlane(rec_type(r1)) == T_SPHERE;
+        if (HAS_NONSPHERE) is_sphere = (UNIFORM ? __builtin_amdgcn_readfirstlane(rec_type(r1)) : rec_type(r1)) == T_SPHERE;
         if (is_sphere) return sphere_occludes(r0, ro, rd, fa);
     }
     float d;
-    if (hittable_hit<HAS_NONSPHERE>(r0, r1, ro, rd, fa, inv, d)) return !LIMITED || d < limit;
+    if (hittable_hit<HAS_NONSPHERE, UNIFORM>(r0, r1, ro, rd, fa, inv, d)) return !LIMITED || d < limit;
     return false;
 }
 
 template <bool HAS_NONSPHERE, bool COUNT, bool LIMITED, int BATCH = 1>
 __device__ __forceinline__ bool any_hit(const SceneLds& sc, v3 ro, v3 rd, float limit, Counters& cnt)
 {
+    if (BATCH == RT_COOP) return any_hit_coop<HAS_NONSPHERE, LIMITED>(sc, ro, rd, limit);
     float fa = 4.0f * dot(rd, rd);
     v3 inv = mk(0, 0, 0);
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     int i = 0;
     if (BATCH > 1) {
         for (; i + BATCH <= sc.n_hit; i += BATCH) {
-            float4 r[2 * BATCH];
+            float4 r[2 * (BATCH > 1 ? BATCH : 1)];
 #pragma unroll
             for (int j = 0; j < 2 * BATCH; ++j) r[j] = sc.urec(2 * i + j);
 #pragma unroll

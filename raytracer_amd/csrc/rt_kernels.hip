@@ -83,7 +83,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
             if (COUNT) ++cnt.closest;
             float dist;
             int bi;
-            if (!HAS_NONSPHERE && primary) bi = closest_hit_primary<COUNT>(sc, rd, dist, cnt);
+            if (!HAS_NONSPHERE && primary && BATCH != RT_COOP) bi = closest_hit_primary<COUNT>(sc, rd, dist, cnt);
             else                           bi = closest_hit<HAS_NONSPHERE, COUNT, BATCH>(sc, ro, rd, dist, cnt);
             primary = false;
             if (bi < 0) {                                                        // renderer.h:40-50
@@ -380,7 +380,7 @@ __device__ __forceinline__ bool heavy_handover(const KernelArgs& a, RNG& rng, un
 // first sample shows a long path are handed to heavy_kernel.
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, bool LDS_RNG, int BATCH, bool HEAVY>
 __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds& sc, float* dirs, unsigned int* rng_lds,
-                                             int x, int y, int r, Counters& cnt)
+                                             int x, int y, int r, Counters& cnt, bool writer = true)
 {
     const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
     typedef RngT<LDS_RNG ? BLOCK : 1> RNG;
@@ -416,7 +416,7 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
             }
         }
     }
-    store_pixel<EMISSION>(a, o, acc_color, acc_em, acc_st);
+    if (writer) store_pixel<EMISSION>(a, o, acc_color, acc_em, acc_st);
 }
 
 template <bool HAS_NONSPHERE, int BATCH = 1>
@@ -764,6 +764,28 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArg
     if (lane == 0) store_pixel<EMISSION>(a, (size_t)o, acc_color, acc_em, acc_st);
 }
 
+// coop_kernel: large scenes.  One wave per listed pixel; all 64 lanes run the pixel's path code on the same values and
+// share every scan of the scene (rt_device.hpp "cooperative scans"), so a bounce costs n/64 tests per lane instead of
+// n tests in one lane's instruction stream.  Lane 0 writes the pixel.
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
+__global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void coop_kernel(KernelArgs a)
+{
+    extern __shared__ float4 lds[];
+    SceneLds sc;
+    float* lds_free;
+    stage_scene(a, lds, sc, lds_free);
+    __builtin_amdgcn_s_setprio(3);
+
+    const unsigned int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (i >= (unsigned int)a.list_count) return;
+    const unsigned int o = a.list[i];
+    const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
+    Counters cnt = { 0, 0, 0, 0, 0 };
+    unsigned int* rng_lds = (unsigned int*)(lds_free + 12 * BLOCK) + threadIdx.x;
+    render_pixel<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, true, RT_COOP, false>(
+        a, sc, lds_free + threadIdx.x, rng_lds, x, frame_row(a, r), r, cnt, (threadIdx.x & 63) == 0);
+}
+
 // resume_kernel: the serial pixel loop for what heavy_kernel gave up on, one lane per pixel, from the sample and the
 // generator state its record names.
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
@@ -1012,6 +1034,22 @@ hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream
         if (e != hipSuccess) return e;                                                                                    \
         return t.deep ? launch_with_lds(resume_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, rblocks, lds, stream)             \
                       : launch_with_lds(resume_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, rblocks, lds, stream); }
+    RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
+    RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)
+    RT_DISPATCH(true, false, false)  RT_DISPATCH(true, false, true)
+    RT_DISPATCH(true, true, false)   RT_DISPATCH(true, true, true)
+#undef RT_DISPATCH
+    return hipErrorInvalidValue;
+}
+
+// coop_kernel over the pixel list: one wave per pixel.
+hipError_t rt_launch_coop(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
+{
+    const int blocks = (a.list_count + BLOCK / 64 - 1) / (BLOCK / 64);
+    const size_t lds = listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+#define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N)                                      \
+        return t.deep ? launch_with_lds(coop_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream)       \
+                      : launch_with_lds(coop_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, stream);
     RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
     RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)
     RT_DISPATCH(true, false, false)  RT_DISPATCH(true, false, true)

@@ -107,6 +107,28 @@ def test_many_objects_small(rt):
     assert np.array_equal(rgb, want_rgb) and np.array_equal(em.view(np.uint32), want_em.view(np.uint32)) and {k: cnt[k] for k in want_cnt} == want_cnt
 
 
+def test_large_scene_cooperative_route(rt):
+    """Scenes with >= 256 hittables render their bounce pixels one wave per pixel, the lanes sharing every scan of the
+    scene (coop_kernel).  Same bytes as the oracle; a NaN-radius sphere forces the sequential fallback of the
+    cooperative closest-hit query (the order of replacements matters once a distance is NaN)."""
+    sc = scenes.many_objects(n=300, n_lights=8, seed=11)
+    W, H, samples, depth, seed = 128, 72, 3, 8, 4
+    want_rgb, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, seed, threads=8)
+    rt.upload_scene(sc)
+    rgb, em, _ = rt.render(W, H, samples, depth, seed, emission=True)
+    assert np.array_equal(rgb, want_rgb) and np.array_equal(em.view(np.uint32), want_em.view(np.uint32))
+    rgb, _, _ = rt.render(W, H, samples, depth, seed)
+    assert np.array_equal(rgb, want_rgb)
+
+    sc = scenes.many_objects(n=280, n_lights=2, seed=5)
+    sc.sphere((1.0, 1.0, -6.0), float("nan"), 2)
+    sc.sphere((-2.0, 0.7, -3.0), 0.7, 3)
+    want_rgb, want_em, _ = oracle_lib.render(sc, 96, 54, 2, 6, 1, threads=8)
+    rt.upload_scene(sc)
+    rgb, em, _ = rt.render(96, 54, 2, 6, 1, emission=True)
+    assert np.array_equal(rgb, want_rgb) and np.array_equal(em.view(np.uint32), want_em.view(np.uint32))
+
+
 def test_executed_tally_prunes_only_shadow_queries(rt):
     """RT_FLAG_COUNT_EXECUTED tallies the production kernel: same image, same closest-hit / draw counts, fewer (or
     equal) shadow queries and primitive tests than the reference issues."""
