@@ -281,6 +281,8 @@ __device__ __forceinline__ Hit hit_record(const SceneLds& sc, int idx, v3 ro, v3
 
 template <bool HAS_NONSPHERE>
 __device__ __forceinline__ int closest_hit_seq(const SceneLds& sc, v3 ro, v3 rd, float& best);
+template <bool HAS_NONSPHERE, bool COUNT, bool LIMITED, bool UNIFORM = true>
+__device__ __forceinline__ bool occluder_hit(float4 r0, float4 r1, v3 ro, v3 rd, float fa, v3 inv, float limit);
 
 template <bool HAS_NONSPHERE>
 __device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd, float& best)
@@ -411,7 +413,7 @@ __device__ __forceinline__ int closest_hit_primary(const SceneLds& sc, v3 rd, fl
 
 // HittablesList::hasIntersect (hittablesList.h:39-50): first hittable whose intersect() is true, no distance bound.
 // With `limit`: the point-light occlusion test "some hittable is hit strictly closer than the light".
-template <bool HAS_NONSPHERE, bool COUNT, bool LIMITED, bool UNIFORM = true>
+template <bool HAS_NONSPHERE, bool COUNT, bool LIMITED, bool UNIFORM>
 __device__ __forceinline__ bool occluder_hit(float4 r0, float4 r1, v3 ro, v3 rd, float fa, v3 inv, float limit)
 {
     if (!LIMITED) {

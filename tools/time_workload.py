@@ -22,9 +22,14 @@ rt = ra.Renderer(0)
 rt.upload_scene(scene)
 cam = ra.camera35f(scene, W, H)
 out = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+ranks = int(os.environ.get("RT_EMULATE_RANKS", "1"))       # time rank 0's share of an N-GPU frame (cyclic 16-row bands)
 for f in flags:
-    p = rt.params(W, H, samples, depth, 0, flags=f)
-    for rep in range(2):
+    if ranks > 1:
+        from raytracer_amd import bands
+        p = bands.band_params(rt, W, H, samples, depth, 0, 16, ranks, 0, flags=f)
+    else:
+        p = rt.params(W, H, samples, depth, 0, flags=f)
+    for rep in range(3):
         t0 = time.perf_counter()
         rt.render_rows(cam, p, out)
         print("%s flags %d: wall %.1f ms, device %.1f ms, checksum %d" % (wl, f, (time.perf_counter() - t0) * 1e3, rt.last_device_ms,
