@@ -136,7 +136,8 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
     a.rgb = nullptr; a.emission = nullptr; a.counters = ctx->d_counters; a.fault = ctx->d_fault;
     a.keys = nullptr; a.hist = nullptr; a.list = nullptr; a.list_count = 0; a.list_count_dev = nullptr;
     a.fallback_count = nullptr; a.fallback_list = nullptr; a.listed_mode = 0;
-    a.heavy_count = nullptr; a.heavy_rec = nullptr; a.heavy_state = nullptr; a.heavy_cap = 0; a.heavy_min_work = 0;
+    a.heavy_count = nullptr; a.heavy_rec = nullptr; a.heavy_pool = nullptr; a.heavy_pool_used = nullptr;
+    a.heavy_pool_words = 0; a.heavy_cap = 0; a.heavy_min_work = 0;
     a.prim = ctx->d_prim;
 }
 
@@ -421,17 +422,17 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                 const bool coop = ctx->n_hit >= RT_COOP_MIN_HIT && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)
                                   && !force;
                 if (!coop && p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
-                    // table: one generator state (128 B) per remaining sample of every handed-over pixel
-                    const size_t entries = (size_t)(p->samples - RT_HEAVY_PROBE);
-                    size_t cap = RT_HEAVY_TABLE_BYTES / (entries * 128);
-                    if (cap > RT_HEAVY_CAP) cap = RT_HEAVY_CAP;
-                    if (cap > n_listed) cap = n_listed;
-                    rc = grow(ctx, &ctx->d_heavy, &ctx->heavy_bytes, 16 + cap * 4 * (entries * 32 + RT_HEAVY_REC_WORDS + 1));
+                    // records + a pool for the pixels' written-out rand() sequences
+                    size_t cap = n_listed < RT_HEAVY_CAP ? n_listed : RT_HEAVY_CAP;
+                    const size_t pool_words = RT_HEAVY_TABLE_BYTES / 4;
+                    rc = grow(ctx, &ctx->d_heavy, &ctx->heavy_bytes, 16 + 4 * (pool_words + cap * (RT_HEAVY_REC_WORDS + 1)));
                     if (rc) return rc;
                     g2.heavy_count = (unsigned int*)ctx->d_heavy;
                     g2.fallback_count = g2.heavy_count + 1;
-                    g2.heavy_state = g2.heavy_count + 4;
-                    g2.heavy_rec = g2.heavy_state + cap * (entries * 32);
+                    g2.heavy_pool_used = (unsigned long long*)(g2.heavy_count + 2);
+                    g2.heavy_pool = g2.heavy_count + 4;
+                    g2.heavy_pool_words = (unsigned int)pool_words;
+                    g2.heavy_rec = g2.heavy_pool + pool_words;
                     g2.fallback_list = g2.heavy_rec + cap * RT_HEAVY_REC_WORDS;
                     g2.heavy_cap = (int)cap;
                     // the threshold is tuned on DEFAULT-4 (4 hittables, 1 light: 8 primitive tests per query pair);

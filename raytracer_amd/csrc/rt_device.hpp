@@ -139,6 +139,65 @@ struct RngT {
 
 typedef RngT<1> Rng;   // words in a private (scratch) array
 
+// The same generator read from a *stream*: the raw words r[i] = r[i-3] + r[i-31] written out in order (word 31 + n of
+// the stream is draw n; the first 31 words are the state the stream starts from).  A lane that knows the index of its
+// first draw needs no private generator state, so many lanes can draw from one pixel's sequence at guessed offsets
+// (heavy_kernel).  Words come through a 32-word LDS window per lane (word k at win[k * STRIDE]).
+template <int STRIDE>
+struct RngStreamT {
+    const unsigned int* src;   // the stream (31 state words, then the draws)
+    unsigned int* win;
+    unsigned int off;          // index of the next draw
+    unsigned int lim;          // draws written so far
+    unsigned int cap;          // draws the stream's buffer holds
+    int pos;                   // next word of the window; 32 = empty
+    bool seeded;               // always true: the stream is what srand() + earlier draws left
+    bool overflow;             // drew past lim: the values were not the generator's
+    unsigned int ndraws;
+
+    __device__ __forceinline__ void start(const unsigned int* stream, unsigned int* window, unsigned int first_draw,
+                                          unsigned int written, unsigned int capacity)
+    {
+        src = stream; win = window; off = first_draw; lim = written; cap = capacity;
+        pos = 32; seeded = true; overflow = false; ndraws = 0;
+    }
+    __device__ __forceinline__ void do_seed() {}
+
+    __device__ __forceinline__ void refill()
+    {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            unsigned int i = off + (unsigned int)k;
+            if (i >= cap) i = cap - 1;             // stay inside the buffer; such draws are flagged by `overflow`
+            win[k * STRIDE] = src[31 + i];
+        }
+        pos = 0;
+    }
+
+    __device__ __forceinline__ void next3(int& o0, int& o1, int& o2)
+    {
+        if (pos > 29) refill();
+        unsigned int v0 = win[pos * STRIDE], v1 = win[(pos + 1) * STRIDE], v2 = win[(pos + 2) * STRIDE];
+        pos += 3; off += 3; ndraws += 3;
+        if (off > lim) overflow = true;
+        o0 = (int)(v0 >> 1); o1 = (int)(v1 >> 1); o2 = (int)(v2 >> 1);
+    }
+};
+
+// Appends 31 * turns words to a stream whose last 31 words precede `out` (out[-31 .. -1]).
+__device__ __noinline__ static void stream_turns(unsigned int* out, int turns)
+{
+    unsigned int t[31];
+#pragma unroll
+    for (int k = 0; k < 31; ++k) t[k] = out[k - 31];
+#pragma unroll 1
+    for (int turn = 0; turn < turns; ++turn) {
+#pragma unroll
+        for (int n = 0; n < 31; ++n) { t[n] += t[(n + 28) % 31]; out[n] = t[n]; }
+        out += 31;
+    }
+}
+
 // randomUnit() = (float)rand() / (float)RAND_MAX, (float)RAND_MAX == 2^31 (rand.h:9)
 __device__ __forceinline__ float rand_unit(int r) { return (float)r * 4.656612873077392578125e-10f; }
 

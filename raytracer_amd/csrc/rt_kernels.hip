@@ -34,11 +34,9 @@ constexpr int BLOCK = 256;
 #ifndef RT_LISTED_WAVES
 #define RT_LISTED_WAVES 4
 #endif
-// sample-parallel pixels: at most this many samples (one wave, one lane per sample)
-#define RT_HEAVY_SAMPLES 64
-// re-guesses per pixel before it is sent back to the serial kernel
-#ifndef RT_HEAVY_ROUNDS
-#define RT_HEAVY_ROUNDS 4
+// 1: only pixels whose first samples all drew the same count are handed over
+#ifndef RT_HEAVY_NEED_STEADY
+#define RT_HEAVY_NEED_STEADY 1
 #endif
 
 struct PathOut { v3 color, emission; float strength; int maxDepth; };
@@ -347,30 +345,33 @@ __device__ __forceinline__ void store_pixel(const KernelArgs& a, size_t o, v3 ac
         a.emission[o] = make_float4(acc_em.x / n, acc_em.y / n, acc_em.z / n, acc_st / n);
 }
 
-// Hands a long pixel over to heavy_kernel (DESIGN.md "sample-parallel pixels").  Called after the first
-// RT_HEAVY_PROBE samples, which drew d0 numbers each: the generator state at the start of sample s is recorded for
-// every later s, on the guess that every sample draws d0 numbers; heavy_kernel checks the guess.  Table entry: 31 words + front slot, one
-// entry per remaining sample; record: pixel, d0, the sums over the samples done.  Returns false when the table is full (the
-// caller then carries on itself).
+// Hands a long pixel over to heavy_kernel (DESIGN.md "sample-parallel pixels") after its first RT_HEAVY_PROBE
+// samples.  The pixel gets a stretch of the stream pool that starts with the generator's 31 state words in the order
+// they were written (oldest first: the stream continues them, rt_device.hpp RngStreamT), and a record: pixel, the draw
+// count to guess per sample, the sums over the samples done, the next sample, where its stream lies and how many draws
+// it holds, the draw index the next sample starts at, draws written so far.  Returns false when the pool or the record
+// table is full (the caller then carries on itself).
 template <class RNG>
-__device__ __forceinline__ bool heavy_handover(const KernelArgs& a, RNG& rng, unsigned int pixel, unsigned int d0,
+__device__ __forceinline__ bool heavy_handover(const KernelArgs& a, RNG& rng, unsigned int pixel, unsigned int guess,
                                                v3 acc_color, v3 acc_em, float acc_st)
 {
+    // room for twice the guessed number of draws of the remaining samples, in whole turns of 31
+    unsigned int cap = (unsigned int)(a.samples - RT_HEAVY_PROBE) * guess * 2u + 124u;
+    cap -= cap % 31u;
+    const unsigned int need = 31u + cap;
+    const unsigned long long base = atomicAdd(a.heavy_pool_used, (unsigned long long)need);
+    if (base + need > (unsigned long long)a.heavy_pool_words) return false;
     const unsigned int h = atomicAdd(a.heavy_count, 1u);
     if (h >= (unsigned int)a.heavy_cap) return false;
+    unsigned int* st = a.heavy_pool + base;
+    int f = rng.f;
+    for (int k = 0; k < 31; ++k) { st[k] = rng.r[f * RNG::stride]; f = RNG::wrap(f + 1); }
     unsigned int* rec = a.heavy_rec + (size_t)h * RT_HEAVY_REC_WORDS;
-    rec[0] = pixel; rec[1] = d0;
+    rec[0] = pixel; rec[1] = guess;
     rec[2] = __float_as_uint(acc_color.x); rec[3] = __float_as_uint(acc_color.y); rec[4] = __float_as_uint(acc_color.z);
     rec[5] = __float_as_uint(acc_em.x); rec[6] = __float_as_uint(acc_em.y); rec[7] = __float_as_uint(acc_em.z);
     rec[8] = __float_as_uint(acc_st);
-    unsigned int* tab = a.heavy_state + (size_t)h * (a.samples - RT_HEAVY_PROBE) * 32;
-    for (int s = RT_HEAVY_PROBE; s < a.samples; ++s) {
-        unsigned int* e = tab + (s - RT_HEAVY_PROBE) * 32;
-        for (int k = 0; k < 31; ++k) e[k] = rng.r[k * RNG::stride];
-        e[31] = (unsigned int)rng.f;
-        if (s + 1 < a.samples)
-            for (unsigned int i = 0; i < d0; ++i) (void)rng.next();
-    }
+    rec[9] = RT_HEAVY_PROBE; rec[10] = (unsigned int)base; rec[11] = cap; rec[12] = 0u; rec[13] = 0u;
     return true;
 }
 
@@ -398,6 +399,7 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
     unsigned int d0 = 0;
     bool steady = true;
     for (int s = 0; s < a.samples; ++s) {
+        const unsigned int before = rng.ndraws;
         SampleOut so = render_sample<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, RNG, BATCH>(a, sc, rng, dirs, origin, cnt);
         acc_color = acc_color + so.color;
         if (EMISSION) { acc_em = acc_em + so.emission; acc_st += so.strength; }
@@ -408,11 +410,14 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
             if (s == 0) d0 = rng.ndraws;
             steady = steady && rng.ndraws == (unsigned int)(s + 1) * d0;
             if (s == RT_HEAVY_PROBE - 1) {
-                const bool eligible = steady && d0 > 0
-                    && (unsigned long long)d0 * (unsigned int)(a.samples - RT_HEAVY_PROBE) >= (unsigned long long)a.heavy_min_work;
+                // the guess for the draws of one sample: what this last sample drew
+                const unsigned int guess = rng.ndraws - before;
+                // (the test hook, threshold 0, also hands over pixels whose counts differ: the re-guess path)
+                const bool eligible = guess > 0 && (steady || !RT_HEAVY_NEED_STEADY || a.heavy_min_work == 0)
+                    && (unsigned long long)guess * (unsigned int)(a.samples - RT_HEAVY_PROBE) >= (unsigned long long)a.heavy_min_work;
                 if (a.listed_mode == RT_MODE_REST) { if (eligible) return; }
                 else if (!eligible) return;
-                else if (heavy_handover(a, rng, (unsigned int)o, d0, acc_color, acc_em, acc_st)) return;
+                else if (heavy_handover(a, rng, (unsigned int)o, guess, acc_color, acc_em, acc_st)) return;
             }
         }
     }
@@ -653,11 +658,95 @@ __global__ __launch_bounds__(BLOCK, LISTED ? RT_LISTED_WAVES : RT_MIN_WAVES) voi
 }
 
 // heavy_kernel: one wave per handed-over pixel, one lane per sample (DESIGN.md "sample-parallel pixels").  A pixel's
-// samples share one rand() stream, so sample s can only start where sample s-1 stopped; the hand-over guessed those
-// starting states d0 draws apart.  Every lane traces its sample from its guessed state and counts its draws: up to and
-// including the first lane whose count is not d0 the guesses were right.  That lane's final state is the true start of
-// the next sample; it re-guesses the later lanes' states from there and they trace again, until all samples stand.
-// The sample results are then added in sample order by one lane, like the serial loop does.
+// samples share one rand() sequence, so sample s can only start where sample s-1 stopped.  The wave writes the
+// sequence out as a stream (lane 0, ahead of need) and every lane traces its sample from a *guessed* draw index:
+// `guess` draws per sample.  Up to and including the first lane whose draw count is not `guess` the indices were
+// right; those samples stand and are added, in sample order, to the pixel's sums.  The next sample's true index is then
+// known, the later lanes re-guess from it and trace again -- a round costs one sample's path and settles at least one
+// sample, more when the draw counts repeat.  A pixel whose rounds settle too few samples (the more pixels wait, the
+// more is asked) is handed on to resume_kernel with its progress.
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
+__device__ __forceinline__ void heavy_pixel(const KernelArgs& a, const SceneLds& sc, float* lds_free, unsigned int h, int need_rate)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned int* rec = a.heavy_rec + (size_t)h * RT_HEAVY_REC_WORDS;
+    const unsigned int o = rec[0], guess = rec[1], cap = rec[11];
+    unsigned int* stream = a.heavy_pool + rec[10];
+    const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
+    float* dirs = lds_free + threadIdx.x;
+    primary_directions(a, dirs, x, frame_row(a, r));                         // every lane: the same pixel
+    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+    unsigned int* win = (unsigned int*)(lds_free + 12 * BLOCK) + threadIdx.x;
+
+    v3 acc_color = mk(__uint_as_float(rec[2]), __uint_as_float(rec[3]), __uint_as_float(rec[4]));
+    v3 acc_em = mk(__uint_as_float(rec[5]), __uint_as_float(rec[6]), __uint_as_float(rec[7]));
+    float acc_st = __uint_as_float(rec[8]);
+    int first = (int)rec[9];                  // samples below `first` stand
+    unsigned int first_draw = rec[12];        // draw index sample `first` starts at
+    unsigned int written = rec[13];           // draws in the stream so far
+    const int first0 = first;
+    unsigned int extra = 0;                   // more stream than the guesses ask for, after a sample ran out of it
+
+    Counters cnt = { 0, 0, 0, 0, 0 };
+    typedef RngStreamT<BLOCK> RNG;
+    for (int round = 1;; ++round) {
+        const bool mine = lane >= first && lane < a.samples;
+        const unsigned int my_draw = first_draw + (unsigned int)(mine ? lane - first : 0) * guess;
+        // the stream must cover every guessed sample and some slack for samples that draw more
+        unsigned int want = first_draw + (unsigned int)(a.samples - first) * guess + 2u * guess + extra;
+        if (want > cap) want = cap;
+        if (written < want) {
+            const int turns = (int)((want - written + 30u) / 31u);           // cap is a whole number of turns
+            if (lane == 0) stream_turns(stream + 31 + written, turns);
+            written += 31u * (unsigned int)turns;
+            __threadfence();
+        }
+        RNG rng;
+        rng.start(stream, win, my_draw, written, cap);
+        SampleOut so;
+        so.color = mk(0, 0, 0); so.emission = mk(0, 0, 0); so.strength = 0.0f;
+        if (mine) so = render_sample<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, RNG, RT_LISTED_BATCH>(a, sc, rng, dirs, origin, cnt);
+
+        // lanes up to the first one that is off started at their true index; that one stands too unless it ran out of
+        // stream (its numbers were not the generator's)
+        const unsigned long long off = __ballot(mine && (rng.overflow || rng.ndraws != guess));
+        int last = a.samples - 1;
+        bool starved = false;
+        if (off != 0ull) {
+            const int sb = __ffsll((long long)off) - 1;
+            starved = __shfl((int)rng.overflow, sb) != 0;
+            last = starved ? sb - 1 : sb;
+        }
+        for (int s = first; s <= last; ++s) {                                // main.cpp:313-315: sums in sample order
+            acc_color = acc_color + mk(__shfl(so.color.x, s), __shfl(so.color.y, s), __shfl(so.color.z, s));
+            if (EMISSION) {
+                acc_em = acc_em + mk(__shfl(so.emission.x, s), __shfl(so.emission.y, s), __shfl(so.emission.z, s));
+                acc_st += __shfl(so.strength, s);
+            }
+        }
+        if (last >= first) first_draw = (unsigned int)__shfl((int)(my_draw + rng.ndraws), last);
+        first = last + 1;
+        if (first >= a.samples) break;
+
+        bool give_up = round >= 3 && first - first0 < need_rate * round;
+        if (starved) {
+            if (written >= cap) give_up = true;          // the pixel draws more than its stream holds
+            extra += 4u * guess;
+        }
+        if (give_up) {
+            if (lane == 0) {
+                rec[2] = __float_as_uint(acc_color.x); rec[3] = __float_as_uint(acc_color.y); rec[4] = __float_as_uint(acc_color.z);
+                rec[5] = __float_as_uint(acc_em.x); rec[6] = __float_as_uint(acc_em.y); rec[7] = __float_as_uint(acc_em.z);
+                rec[8] = __float_as_uint(acc_st);
+                rec[9] = (unsigned int)first; rec[12] = first_draw; rec[13] = written;
+                a.fallback_list[atomicAdd(a.fallback_count, 1u)] = h;
+            }
+            return;
+        }
+    }
+    if (lane == 0) store_pixel<EMISSION>(a, (size_t)o, acc_color, acc_em, acc_st);
+}
+
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
 __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArgs a)
 {
@@ -669,99 +758,12 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArg
     float* lds_free;
     stage_scene(a, lds, sc, lds_free);
     __builtin_amdgcn_s_setprio(3);
-
-    const int lane = threadIdx.x & 63;
     const unsigned int h = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (h >= count) return;
-    const unsigned int* rec = a.heavy_rec + (size_t)h * RT_HEAVY_REC_WORDS;
-    const unsigned int o = rec[0], d0 = rec[1];
-    const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
-    const int y = frame_row(a, r);
-    float* dirs = lds_free + threadIdx.x;
-    primary_directions(a, dirs, x, y);                                       // every lane: the same pixel
-    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
-
-    // generator words in LDS: word k of thread t at [k*BLOCK + t], k = 31 holds the front slot while states are passed
-    unsigned int* slots = (unsigned int*)(lds_free + 12 * BLOCK) + threadIdx.x;
-    const bool active = lane >= RT_HEAVY_PROBE && lane < a.samples;      // the first samples came with the hand-over
-    typedef RngT<BLOCK> RNG;
-    RNG rng;
-    rng.init(slots, 0u);
-    rng.seeded = true;
-    if (active) {
-        const unsigned int* e = a.heavy_state + ((size_t)h * (a.samples - RT_HEAVY_PROBE) + (lane - RT_HEAVY_PROBE)) * 32;
-        for (int k = 0; k < 31; ++k) slots[k * BLOCK] = e[k];
-        rng.f = (int)e[31];
-    }
-
-    Counters cnt = { 0, 0, 0, 0, 0 };
-    SampleOut so;
-    so.color = mk(0, 0, 0); so.emission = mk(0, 0, 0); so.strength = 0.0f;
-    int first = RT_HEAVY_PROBE;         // samples below `first` stand
-    for (int round = 0;; ++round) {
-        const bool mine = active && lane >= first;
-        if (mine) {
-            rng.ndraws = 0;
-            so = render_sample<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, RNG, RT_LISTED_BATCH>(a, sc, rng, dirs, origin, cnt);
-        }
-        const unsigned long long off = __ballot(mine && rng.ndraws != d0);
-        if (off == 0ull) break;
-        const int sb = __ffsll((long long)off) - 1;      // sample sb started right, so it stands; sb + 1 starts where it stopped
-        if (sb + 1 >= a.samples) break;
-        if (round == RT_HEAVY_ROUNDS || __popcll(off) > RT_HEAVY_ROUNDS - round) {
-            // the guess keeps failing: this pixel's draws depend on the numbers drawn.  Samples up to sb stand; the
-            // rest goes to resume_kernel, serially, from the state sample sb stopped in.
-            v3 acc_color = mk(__uint_as_float(rec[2]), __uint_as_float(rec[3]), __uint_as_float(rec[4]));
-            v3 acc_em = mk(__uint_as_float(rec[5]), __uint_as_float(rec[6]), __uint_as_float(rec[7]));
-            float acc_st = __uint_as_float(rec[8]);
-            for (int s = RT_HEAVY_PROBE; s <= sb; ++s) {
-                acc_color = acc_color + mk(__shfl(so.color.x, s), __shfl(so.color.y, s), __shfl(so.color.z, s));
-                if (EMISSION) {
-                    acc_em = acc_em + mk(__shfl(so.emission.x, s), __shfl(so.emission.y, s), __shfl(so.emission.z, s));
-                    acc_st += __shfl(so.strength, s);
-                }
-            }
-            if (lane == sb) {
-                unsigned int* e = a.heavy_state + ((size_t)h * (a.samples - RT_HEAVY_PROBE) + (sb + 1 - RT_HEAVY_PROBE)) * 32;
-                for (int k = 0; k < 31; ++k) e[k] = slots[k * BLOCK];
-                e[31] = (unsigned int)rng.f;
-                unsigned int* w = a.heavy_rec + (size_t)h * RT_HEAVY_REC_WORDS;
-                w[2] = __float_as_uint(acc_color.x); w[3] = __float_as_uint(acc_color.y); w[4] = __float_as_uint(acc_color.z);
-                w[5] = __float_as_uint(acc_em.x); w[6] = __float_as_uint(acc_em.y); w[7] = __float_as_uint(acc_em.z);
-                w[8] = __float_as_uint(acc_st);
-                w[9] = (unsigned int)(sb + 1);
-                a.fallback_list[atomicAdd(a.fallback_count, 1u)] = h;
-            }
-            return;
-        }
-        if (lane == sb) {
-            unsigned int* dst = slots;
-            for (int s = sb + 1; s < a.samples; ++s) {
-                ++dst;                                   // thread t + 1's slots
-                for (int k = 0; k < 31; ++k) dst[k * BLOCK] = slots[k * BLOCK];
-                dst[31 * BLOCK] = (unsigned int)rng.f;
-                if (s + 1 < a.samples)
-                    for (unsigned int i = 0; i < d0; ++i) (void)rng.next();
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (active && lane > sb) rng.f = (int)slots[31 * BLOCK];
-        first = sb + 1;
-    }
-
-    // main.cpp:313-315: the sums run in sample order
-    v3 acc_color = mk(__uint_as_float(rec[2]), __uint_as_float(rec[3]), __uint_as_float(rec[4]));
-    v3 acc_em = mk(__uint_as_float(rec[5]), __uint_as_float(rec[6]), __uint_as_float(rec[7]));
-    float acc_st = __uint_as_float(rec[8]);
-    for (int s = RT_HEAVY_PROBE; s < a.samples; ++s) {
-        acc_color = acc_color + mk(__shfl(so.color.x, s), __shfl(so.color.y, s), __shfl(so.color.z, s));
-        if (EMISSION) {
-            acc_em = acc_em + mk(__shfl(so.emission.x, s), __shfl(so.emission.y, s), __shfl(so.emission.z, s));
-            acc_st += __shfl(so.strength, s);
-        }
-    }
-    if (lane == 0) store_pixel<EMISSION>(a, (size_t)o, acc_color, acc_em, acc_st);
+    // samples a round must settle on average: 2 while the pixels fit on the GPU at once, more when they queue
+    int need_rate = (int)(count / 512u);
+    need_rate = need_rate < 2 ? 2 : need_rate > 16 ? 16 : need_rate;
+    heavy_pixel<EMISSION, MIXED, HAS_NONSPHERE, MAXSP, MAXPEND>(a, sc, lds_free, h, need_rate);
 }
 
 // coop_kernel: large scenes.  One wave per listed pixel; all 64 lanes run the pixel's path code on the same values and
@@ -786,8 +788,8 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void coop_kernel(KernelArgs
         a, sc, lds_free + threadIdx.x, rng_lds, x, frame_row(a, r), r, cnt, (threadIdx.x & 63) == 0);
 }
 
-// resume_kernel: the serial pixel loop for what heavy_kernel gave up on, one lane per pixel, from the sample and the
-// generator state its record names.
+// resume_kernel: the serial pixel loop for what heavy_kernel gave up on, one lane per pixel, from the sample its record
+// names and the generator state found in the pixel's stream.
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
 __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void resume_kernel(KernelArgs a)
 {
@@ -815,9 +817,10 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void resume_kernel(KernelAr
     RNG rng;
     rng.init(slots, 0u);
     rng.seeded = true;
-    const unsigned int* e = a.heavy_state + ((size_t)h * (a.samples - RT_HEAVY_PROBE) + (next - RT_HEAVY_PROBE)) * 32;
+    // the 31 words before the next sample's first draw, oldest first, are the generator's state (front slot 0)
+    const unsigned int* e = a.heavy_pool + rec[10] + rec[12];
     for (int k = 0; k < 31; ++k) slots[k * BLOCK] = e[k];
-    rng.f = (int)e[31];
+    rng.f = 0;
 
     Counters cnt = { 0, 0, 0, 0, 0 };
     v3 acc_color = mk(__uint_as_float(rec[2]), __uint_as_float(rec[3]), __uint_as_float(rec[4]));

@@ -10,7 +10,7 @@
 // deep serves RT_MAX_DEPTH (64).
 // pixel classes: 0 = direct, 1 + material index (RT_MAX_MATERIALS = 256)
 #define RT_MAX_KEYS 257
-#define RT_HEAVY_REC_WORDS 12
+#define RT_HEAVY_REC_WORDS 16
 #define RT_HEAVY_PROBE 4      /* samples the listed kernel does before a pixel can be handed over */
 // the listed render_kernel runs twice over the same list when long pixels are handed over (heavy_cap > 0)
 #define RT_MODE_STEADY 1   /* owns the pixels whose first samples draw equal counts and are long: hands them over */
@@ -43,8 +43,10 @@ struct KernelArgs {
     const unsigned int* list_count_dev;  // if not null: the list length lives on the device (list_count = capacity)
     // sample-parallel pixels (listed render_kernel -> heavy_kernel); heavy_cap == 0 switches the hand-over off
     unsigned int* heavy_count;   // pixels handed over (may run past heavy_cap: those were not handed over)
-    unsigned int* heavy_rec;     // heavy_cap x RT_HEAVY_REC_WORDS: pixel, draws per sample, sums over the samples done
-    unsigned int* heavy_state;   // heavy_cap x (samples - RT_HEAVY_PROBE) x 32 words: generator state at the start of each sample
+    unsigned int* heavy_rec;     // heavy_cap x RT_HEAVY_REC_WORDS (heavy_handover in rt_kernels.hip lists the fields)
+    unsigned int* heavy_pool;    // stream pool: each handed-over pixel's rand() sequence, written out
+    unsigned long long* heavy_pool_used;   // words of the pool given out (may run past heavy_pool_words: those got none)
+    unsigned int heavy_pool_words;
     int heavy_cap;
     unsigned int heavy_min_work; // hand over when draws(sample 0) * (samples left) reaches this
     unsigned int* fallback_count;// pixels heavy_kernel gave up on ...
