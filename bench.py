@@ -127,6 +127,7 @@ def main():
     rpr = bands.rows_per_rank(H, BAND_ROWS, world)
     p = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank, flags=args.flags)
     block = torch.zeros((rpr, W, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()        # the library renders on its own stream: the zero fill must have landed
 
     def step():
         rt.render_rows(cam, p, block)

@@ -9,6 +9,7 @@
  *
  * Conventions: every function returns RT_OK (0) or a negative rt_status; the caller owns every buffer it passes
  * (the library copies what it keeps); a context is bound to one GPU and is not thread-safe; calls are synchronous.
+ * The library works on HIP streams of its own: device buffers passed in must have no work pending on other streams.
  */
 #ifndef RT_AMD_H
 #define RT_AMD_H

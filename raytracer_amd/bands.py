@@ -35,10 +35,7 @@ def deinterleave(gathered, frame, band_rows, nranks, renderer=None):
     tensors (gloo tests) a plain index copy."""
     H = frame.shape[0]
     if gathered.is_cuda:
-        # the library works on its own HIP stream: whatever torch / RCCL still has in flight on this tensor (the
-        # gather lands on torch's current stream) must be complete before the library reads it
-        if nranks > 1:
-            torch.cuda.current_stream(gathered.device).synchronize()
+        # (Renderer waits for torch's current stream -- where the gather lands -- before the library's own stream reads)
         W = frame.shape[1]
         bpp = frame.element_size() * (frame.shape[2] if frame.dim() > 2 else 1)
         renderer.deinterleave_bands(gathered, frame, W, H, bpp, band_rows, nranks, gathered.shape[1])

@@ -33,6 +33,11 @@ def _ptr(buf):
         return buf.ctypes.data
     if hasattr(buf, "data_ptr"):
         assert buf.is_contiguous()
+        if buf.is_cuda:
+            # the library works on its own HIP stream and its calls are synchronous: work torch still has in flight
+            # on this tensor (its zero fill, a collective) must have landed before the library touches it
+            import torch
+            torch.cuda.current_stream(buf.device).synchronize()
         return buf.data_ptr()
     raise TypeError("expected a numpy array or a torch tensor")
 

@@ -22,6 +22,7 @@ rt = ra.Renderer(0)
 rt.upload_scene(scene)
 cam = ra.camera35f(scene, W, H)
 out = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
 ranks = int(os.environ.get("RT_EMULATE_RANKS", "1"))       # time rank 0's share of an N-GPU frame (cyclic 16-row bands)
 for f in flags:
     if ranks > 1:
