@@ -129,6 +129,29 @@ def test_large_scene_cooperative_route(rt):
     assert np.array_equal(rgb, want_rgb) and np.array_equal(em.view(np.uint32), want_em.view(np.uint32))
 
 
+def test_capacity_and_sample_count_edges(rt):
+    """RT_MAX_HITTABLES hittables: the staged scene leaves no LDS for the generators, so the listed kernels keep them in
+    scratch and neither the sample-parallel nor the cooperative route applies.  More than 64 samples per pixel (one
+    wave's lanes) and fewer than 8 also keep every pixel serial; 8 and 64 are the ends of the sample-parallel range."""
+    from raytracer_amd import _abi
+    sc = scenes.many_objects(n=4095, n_lights=2, seed=3)
+    assert len(sc.hittables) == 4096
+    want, want_em, _ = oracle_lib.render(sc, 48, 24, 2, 4, 7, threads=8)
+    rt.upload_scene(sc)
+    rgb, em, _ = rt.render(48, 24, 2, 4, 7, emission=True)
+    assert np.array_equal(rgb, want) and np.array_equal(em.view(np.uint32), want_em.view(np.uint32))
+
+    sc = scenes.glass_mirror()
+    rt.upload_scene(sc)
+    cam = ra.camera35f(sc, 64, 36)
+    for samples in (70, 7, 8, 64):
+        want, _, _ = oracle_lib.render(sc, 64, 36, samples, 8, 2, threads=8)
+        for flags in (0, _abi.RT_FLAG_FORCE_SAMPLE_PARALLEL):
+            got = np.zeros((36, 64, 3), np.uint8)
+            rt.render_rows(cam, rt.params(64, 36, samples, 8, 2, flags=flags), got)
+            assert np.array_equal(got, want), (samples, flags)
+
+
 def test_executed_tally_prunes_only_shadow_queries(rt):
     """RT_FLAG_COUNT_EXECUTED tallies the production kernel: same image, same closest-hit / draw counts, fewer (or
     equal) shadow queries and primitive tests than the reference issues."""
