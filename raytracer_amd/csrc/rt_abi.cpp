@@ -419,7 +419,7 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                 // one lane per sample, by the heavy kernel behind it (DESIGN.md "sample-parallel pixels").
                 const bool force = (p->flags & RT_FLAG_FORCE_SAMPLE_PARALLEL) != 0;
                 // Large scenes: one wave per listed pixel, the lanes share every scan of the scene (coop_kernel)
-                const bool coop = ctx->n_hit >= RT_COOP_MIN_HIT && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)
+                const bool coop = ctx->n_hit >= RT_COOP_MIN_HIT && rt_launch_coop_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)
                                   && !force;
                 if (!coop && p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
                     // records + a pool for the pixels' written-out rand() sequences

@@ -222,9 +222,10 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     float4* l_lights = l_hrec + nrec;
     float* l_mats = (float*)(l_lights + a.n_lights);
     const int nm = 10 * a.n_mat;
-    for (int i = threadIdx.x; i < nrec; i += BLOCK) l_hrec[i] = a.hrec[i];
-    for (int i = threadIdx.x; i < a.n_lights; i += BLOCK) l_lights[i] = a.lights[i];
-    for (int i = threadIdx.x; i < nm; i += BLOCK) l_mats[i] = a.mats[i];
+    const int nthreads = (int)blockDim.x;
+    for (int i = threadIdx.x; i < nrec; i += nthreads) l_hrec[i] = a.hrec[i];
+    for (int i = threadIdx.x; i < a.n_lights; i += nthreads) l_lights[i] = a.lights[i];
+    for (int i = threadIdx.x; i < nm; i += nthreads) l_mats[i] = a.mats[i];
     // per-thread words start on the next 16-byte boundary
     lds_free = l_mats + ((nm + 3) & ~3);
     sc.hrec = l_hrec; sc.lights = l_lights; sc.mats = l_mats;
@@ -277,6 +278,7 @@ __device__ __forceinline__ PixelId listed_pixel(const KernelArgs& a)
 }
 
 // The four primary directions of a pixel (renderer.h:140,167,175,183,191 over main.cpp:301-307) into LDS words.
+template <int STRIDE = BLOCK>
 __device__ __forceinline__ void primary_directions(const KernelArgs& a, float* dirs, int x, int y)
 {
     Camera cam;
@@ -292,15 +294,15 @@ __device__ __forceinline__ void primary_directions(const KernelArgs& a, float* d
         float uu = (k & 1) ? u + offX : u - offX;
         float vv = (k & 2) ? v + offY : v - offY;
         v3 d = uv_to_direction(cam, uu, vv);
-        dirs[(3 * k + 0) * BLOCK] = d.x; dirs[(3 * k + 1) * BLOCK] = d.y; dirs[(3 * k + 2) * BLOCK] = d.z;
+        dirs[(3 * k + 0) * STRIDE] = d.x; dirs[(3 * k + 1) * STRIDE] = d.y; dirs[(3 * k + 2) * STRIDE] = d.z;
     }
 }
 
 // One AntiAliasing call (renderer.h:138-201) and the clamps the pixel driver applies to its result (main.cpp:313-315).
-// dirs: the pixel's four primary directions, word j at dirs[j * BLOCK].
+// dirs: the pixel's four primary directions, word j at dirs[j * STRIDE].
 struct SampleOut { v3 color, emission; float strength; };
 
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, class RNG, int BATCH>
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, class RNG, int BATCH, int STRIDE = BLOCK>
 __device__ __forceinline__ SampleOut render_sample(const KernelArgs& a, const SceneLds& sc, RNG& rng, const float* dirs,
                                                    v3 origin, Counters& cnt)
 {
@@ -308,7 +310,7 @@ __device__ __forceinline__ SampleOut render_sample(const KernelArgs& a, const Sc
     float res_st = 0.0f;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {                                            // renderer.h:167-195
-        v3 dir = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+        v3 dir = mk(dirs[(3 * k + 0) * STRIDE], dirs[(3 * k + 1) * STRIDE], dirs[(3 * k + 2) * STRIDE]);
         PathOut p = trace_path<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, RNG, BATCH>(sc, rng, origin, dir, a.max_depth, cnt, a.fault);
         // renderer.h:169: color / vec3(maxDepth); x / 1.0f == x, and most paths end at depth 1
         v3 pc = p.color;
@@ -379,19 +381,19 @@ __device__ __forceinline__ bool heavy_handover(const KernelArgs& a, RNG& rng, un
 // (x, y) of the frame = column x of packed output row r.
 // LDS_RNG: the generator's 31 words live in LDS at rng_lds (slot-major) instead of in scratch.  HEAVY: pixels whose
 // first sample shows a long path are handed to heavy_kernel.
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, bool LDS_RNG, int BATCH, bool HEAVY>
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, bool LDS_RNG, int BATCH, bool HEAVY, int STRIDE = BLOCK>
 __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds& sc, float* dirs, unsigned int* rng_lds,
                                              int x, int y, int r, Counters& cnt, bool writer = true)
 {
     const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
-    typedef RngT<LDS_RNG ? BLOCK : 1> RNG;
+    typedef RngT<LDS_RNG ? STRIDE : 1> RNG;
     unsigned int rng_words[LDS_RNG ? 1 : 31];
     RNG rng;
     rng.init(LDS_RNG ? rng_lds : rng_words, a.seed_base + (unsigned int)(x + y * a.width));   // rand.h:7, main.cpp:304
 
     // AntiAliasing is called with the same (u, v) for every sample (main.cpp:312), so the four primary directions
     // are per-pixel constants: computed once, parked in LDS (12 words per thread, word j of thread t at [j*BLOCK + t]).
-    primary_directions(a, dirs, x, y);
+    primary_directions<STRIDE>(a, dirs, x, y);
 
     const size_t o = (size_t)x + (size_t)r * a.width;
     v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0);
@@ -400,7 +402,7 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
     bool steady = true;
     for (int s = 0; s < a.samples; ++s) {
         const unsigned int before = rng.ndraws;
-        SampleOut so = render_sample<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, RNG, BATCH>(a, sc, rng, dirs, origin, cnt);
+        SampleOut so = render_sample<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, RNG, BATCH, STRIDE>(a, sc, rng, dirs, origin, cnt);
         acc_color = acc_color + so.color;
         if (EMISSION) { acc_em = acc_em + so.emission; acc_st += so.strength; }
         if (HEAVY && a.heavy_cap > 0 && s < RT_HEAVY_PROBE) {
@@ -768,9 +770,14 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArg
 
 // coop_kernel: large scenes.  One wave per listed pixel; all 64 lanes run the pixel's path code on the same values and
 // share every scan of the scene (rt_device.hpp "cooperative scans"), so a bounce costs n/64 tests per lane instead of
-// n tests in one lane's instruction stream.  Lane 0 writes the pixel.
+// n tests in one lane's instruction stream.  Lane 0 writes the pixel.  What the lanes of a wave hold in common -- the
+// pixel's primary directions, the generator's words -- exists once per wave in LDS (every lane reads and writes the
+// same words with the same values), so a workgroup of COOP_WAVES waves needs little more than the staged scene and
+// two of them fit a CU next to a 2049-hittable scene.
+constexpr int COOP_WAVES = 8;
+
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
-__global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void coop_kernel(KernelArgs a)
+__global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
     SceneLds sc;
@@ -778,14 +785,16 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void coop_kernel(KernelArgs
     stage_scene(a, lds, sc, lds_free);
     __builtin_amdgcn_s_setprio(3);
 
-    const unsigned int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const int wave = (int)(threadIdx.x >> 6);
+    const unsigned int i = blockIdx.x * COOP_WAVES + wave;
     if (i >= (unsigned int)a.list_count) return;
     const unsigned int o = a.list[i];
     const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
     Counters cnt = { 0, 0, 0, 0, 0 };
-    unsigned int* rng_lds = (unsigned int*)(lds_free + 12 * BLOCK) + threadIdx.x;
-    render_pixel<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, true, RT_COOP, false>(
-        a, sc, lds_free + threadIdx.x, rng_lds, x, frame_row(a, r), r, cnt, (threadIdx.x & 63) == 0);
+    float* dirs = lds_free + wave;                                           // word j of wave w at [j * COOP_WAVES + w]
+    unsigned int* rng_lds = (unsigned int*)(lds_free + 12 * COOP_WAVES) + wave;
+    render_pixel<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, true, RT_COOP, false, COOP_WAVES>(
+        a, sc, dirs, rng_lds, x, frame_row(a, r), r, cnt, (threadIdx.x & 63) == 0);
 }
 
 // resume_kernel: the serial pixel loop for what heavy_kernel gave up on, one lane per pixel, from the sample its record
@@ -1045,14 +1054,37 @@ hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream
     return hipErrorInvalidValue;
 }
 
+static size_t coop_lds_bytes(int n_hit, int n_lights, int n_mat)
+{
+    size_t nm = (size_t)((10 * n_mat + 3) & ~3);
+    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)(12 + 32) * COOP_WAVES * 4 + 16;
+}
+
+bool rt_launch_coop_fits(int n_hit, int n_lights, int n_mat)
+{
+    return coop_lds_bytes(n_hit, n_lights, n_mat) <= 160 * 1024;
+}
+
+template <class K>
+static hipError_t launch_coop(K k, const KernelArgs& a, int blocks, size_t lds_bytes, hipStream_t stream)
+{
+    if (blocks <= 0) return hipSuccess;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(COOP_WAVES * 64), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
 // coop_kernel over the pixel list: one wave per pixel.
 hipError_t rt_launch_coop(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
 {
-    const int blocks = (a.list_count + BLOCK / 64 - 1) / (BLOCK / 64);
-    const size_t lds = listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
-#define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N)                                      \
-        return t.deep ? launch_with_lds(coop_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream)       \
-                      : launch_with_lds(coop_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, stream);
+    const int blocks = (a.list_count + COOP_WAVES - 1) / COOP_WAVES;
+    const size_t lds = coop_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+#define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N)                                \
+        return t.deep ? launch_coop(coop_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream)       \
+                      : launch_coop(coop_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, stream);
     RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
     RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)
     RT_DISPATCH(true, false, false)  RT_DISPATCH(true, false, true)
