@@ -44,6 +44,7 @@ struct rt_ctx {
     size_t scene_bytes = 0;
     const float4* d_hrec = nullptr; const float4* d_lights = nullptr; const float* d_mats = nullptr;
     float4* d_prim = nullptr;                    // camera-relative sphere terms, refreshed when the camera moves
+    const unsigned int* d_order = nullptr;       // hittable indices sorted by type (cooperative scans)
     std::vector<float> h_centres_r2;             // host copy of (centre, r^2) per hittable
     float prim_cam[3] = { 0, 0, 0 }; bool prim_valid = false;
 
@@ -139,6 +140,7 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
     a.heavy_count = nullptr; a.heavy_rec = nullptr; a.heavy_pool = nullptr; a.heavy_pool_used = nullptr;
     a.heavy_pool_words = 0; a.heavy_cap = 0; a.heavy_min_work = 0;
     a.prim = ctx->d_prim;
+    a.order = ctx->d_order;
 }
 
 // Primary rays all start at the camera: origin - centre and dot(origin, origin) - r*r (sphere.h:15,19) are per-sphere
@@ -271,7 +273,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     }
 
     const int nh = s->n_hittables, nl = s->n_lights, nm = s->n_materials;
-    std::vector<float> img((size_t)nh * 8 + (size_t)nl * 4 + (size_t)nm * 10 + 4 + (size_t)nh * 4, 0.0f);
+    // hrec | lights | mats (padded to 4 floats) | prim (filled per camera) | type-sorted order of the hittables
+    std::vector<float> img((size_t)nh * 8 + (size_t)nl * 4 + (size_t)nm * 10 + 4 + (size_t)nh * 4 + (size_t)nh, 0.0f);
     float* hrec = img.data();
     float* lights = hrec + (size_t)nh * 8;
     float* mats = lights + (size_t)nl * 4;
@@ -315,6 +318,17 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
         std::memcpy(&r[3], &type, 4);
     }
     if (nm > 0) std::memcpy(mats, s->materials, sizeof(float) * 10 * (size_t)nm);
+    // cooperative scans hand hittables to lanes in this order: same type side by side, so the 64 tests of a round
+    // mostly take the same branch (the winner is picked by index, so the order of testing does not matter)
+    const size_t prim_at = (size_t)nh * 8 + (size_t)nl * 4 + (((size_t)nm * 10 + 3) & ~(size_t)3);
+    {
+        std::vector<uint32_t> order;
+        order.reserve((size_t)nh);
+        for (int type = RT_SPHERE; type <= RT_CUBE; ++type)
+            for (int i = 0; i < nh; ++i)
+                if (s->h_type[i] == type) order.push_back((uint32_t)i);
+        if (nh > 0) std::memcpy(&img[prim_at + (size_t)nh * 4], order.data(), sizeof(uint32_t) * (size_t)nh);
+    }
 
     if (rt_launch_lds_bytes(nh, nl, nm) > 160 * 1024) return RT_ERR_UNSUPPORTED;
 
@@ -332,7 +346,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     ctx->d_hrec = (const float4*)ctx->d_scene;
     ctx->d_lights = (const float4*)((const float*)ctx->d_scene + (size_t)nh * 8);
     ctx->d_mats = (const float*)ctx->d_scene + (size_t)nh * 8 + (size_t)nl * 4;
-    ctx->d_prim = (float4*)((float*)ctx->d_scene + (size_t)nh * 8 + (size_t)nl * 4 + (((size_t)nm * 10 + 3) & ~(size_t)3));
+    ctx->d_prim = (float4*)((float*)ctx->d_scene + prim_at);
+    ctx->d_order = (const unsigned int*)((const float*)ctx->d_scene + prim_at + (size_t)nh * 4);
     ctx->h_centres_r2.resize((size_t)nh * 4);
     for (int i = 0; i < nh; ++i) std::memcpy(&ctx->h_centres_r2[4 * (size_t)i], hrec + 8 * (size_t)i, 16);
     ctx->prim_valid = false;

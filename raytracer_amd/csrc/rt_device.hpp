@@ -53,6 +53,7 @@ struct SceneLds {
     int n_hit, n_lights;
     kptr4 khrec, klights; // the same records in global memory, for wave-uniform (scalar) reads
     kptr4 kprim;          // per sphere (camera - centre, |camera - centre|^2 - r^2): primary rays share their origin
+    const unsigned int* order; // hittable indices sorted by type (cooperative scans)
 #ifdef RT_SCALAR_SCENE
     __device__ __forceinline__ float4 urec(int i) const { f32x4 v = khrec[i]; return make_float4(v.x, v.y, v.z, v.w); }
     __device__ __forceinline__ float4 ulight(int i) const { f32x4 v = klights[i]; return make_float4(v.x, v.y, v.z, v.w); }
@@ -353,7 +354,8 @@ __device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd
     best = 3.402823466e+38f;
     int bi = -1;
     bool nan_seen = false;
-    for (int i = lane; i < sc.n_hit; i += 64) {
+    for (int j = lane; j < sc.n_hit; j += 64) {
+        const int i = HAS_NONSPHERE ? (int)sc.order[j] : j;
         float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
         float t;
         if (hittable_hit<HAS_NONSPHERE, false>(r0, r1, ro, rd, fa, inv, t)) {
@@ -382,9 +384,10 @@ __device__ __forceinline__ bool any_hit_coop(const SceneLds& sc, v3 ro, v3 rd, f
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     // 64 hittables per round; the first round with an occluder ends the query (any order gives the same boolean)
     for (int base = 0; base < sc.n_hit; base += 64) {
-        const int i = base + lane;
+        const int j = base + lane;
         bool o = false;
-        if (i < sc.n_hit) {
+        if (j < sc.n_hit) {
+            const int i = HAS_NONSPHERE ? (int)sc.order[j] : j;
             float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
             o = occluder_hit<HAS_NONSPHERE, false, LIMITED, false>(r0, r1, ro, rd, fa, inv, limit);
         }

@@ -231,6 +231,7 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     sc.hrec = l_hrec; sc.lights = l_lights; sc.mats = l_mats;
     sc.n_hit = a.n_hit; sc.n_lights = a.n_lights;
     sc.khrec = (kptr4)a.hrec; sc.klights = (kptr4)a.lights; sc.kprim = (kptr4)a.prim;
+    sc.order = a.order;
     __syncthreads();
 }
 
@@ -927,7 +928,7 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr;
+    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.order = nullptr;
     v3 ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     float4 r0 = hrec[2 * index], r1 = hrec[2 * index + 1];
     float fa = 4.0f * dot(rd, rd);

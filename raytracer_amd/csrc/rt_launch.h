@@ -32,6 +32,7 @@ struct KernelArgs {
     const float4* lights;        // n_lights
     const float* mats;           // 10 * n_mat
     const float4* prim;          // n_hit: per sphere (camera - centre, |camera - centre|^2 - r^2) for primary rays
+    const unsigned int* order;   // n_hit: hittable indices sorted by type, the order cooperative scans deal them to lanes
     unsigned char* rgb;          // rows * width * 3 (probe: width * height flags)
     float4* emission;            // rows * width, or null
     unsigned long long* counters;// 5 words (closest, shadow, tests, draws, shaded), or null
