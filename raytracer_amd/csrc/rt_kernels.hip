@@ -34,10 +34,12 @@ constexpr int BLOCK = 256;
 #ifndef RT_LISTED_WAVES
 #define RT_LISTED_WAVES 4
 #endif
-// 1: only pixels whose first samples all drew the same count are handed over
-#ifndef RT_HEAVY_NEED_STEADY
-#define RT_HEAVY_NEED_STEADY 1
+// how many of the first four samples must have drawn the same count for a pixel to be handed over (measured: with 3
+// or 2, C5 gets slower -- 186 / 210 instead of 175 ms -- and nothing gets faster)
+#ifndef RT_HEAVY_AGREE
+#define RT_HEAVY_AGREE 4
 #endif
+static_assert(RT_HEAVY_PROBE == 4, "render_pixel keeps the counts of exactly four first samples");
 
 struct PathOut { v3 color, emission; float strength; int maxDepth; };
 
@@ -399,24 +401,27 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
     const size_t o = (size_t)x + (size_t)r * a.width;
     v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0);
     float acc_st = 0.0f;
-    unsigned int d0 = 0;
-    bool steady = true;
+    unsigned int c0 = 0, c1 = 0, c2 = 0;          // draws of the first samples
     for (int s = 0; s < a.samples; ++s) {
         const unsigned int before = rng.ndraws;
         SampleOut so = render_sample<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, RNG, BATCH, STRIDE>(a, sc, rng, dirs, origin, cnt);
         acc_color = acc_color + so.color;
         if (EMISSION) { acc_em = acc_em + so.emission; acc_st += so.strength; }
         if (HEAVY && a.heavy_cap > 0 && s < RT_HEAVY_PROBE) {
-            // the first samples all drew the same count: a path whose shape does not hang on the numbers drawn, probably.
-            // Two launches of this kernel share the list: one owns the steady long pixels and hands them over, the
-            // other owns the rest; both learn which is which from the same first samples.
-            if (s == 0) d0 = rng.ndraws;
-            steady = steady && rng.ndraws == (unsigned int)(s + 1) * d0;
+            // The first four samples tell whether the pixel's draw count repeats (a path whose shape does not hang on
+            // the numbers drawn, mostly): at least RT_HEAVY_AGREE of them drew the same count, which becomes the guess.
+            // Two launches of this kernel share the list: one owns the long pixels of that kind and hands them over,
+            // the other owns the rest; both learn which is which from the same first samples.
+            const unsigned int c3 = rng.ndraws - before;
+            if (s == 0) c0 = c3;
+            if (s == 1) c1 = c3;
+            if (s == 2) c2 = c3;
             if (s == RT_HEAVY_PROBE - 1) {
-                // the guess for the draws of one sample: what this last sample drew
-                const unsigned int guess = rng.ndraws - before;
+                unsigned int guess = c3;
+                int agree = 1 + (c0 == c3) + (c1 == c3) + (c2 == c3);
+                if (agree < 3) { guess = c0; agree = (c1 == c0) + (c2 == c0) + 1; }      // three of four: c0 == c1 == c2
                 // (the test hook, threshold 0, also hands over pixels whose counts differ: the re-guess path)
-                const bool eligible = guess > 0 && (steady || !RT_HEAVY_NEED_STEADY || a.heavy_min_work == 0)
+                const bool eligible = guess > 0 && (agree >= RT_HEAVY_AGREE || a.heavy_min_work == 0)
                     && (unsigned long long)guess * (unsigned int)(a.samples - RT_HEAVY_PROBE) >= (unsigned long long)a.heavy_min_work;
                 if (a.listed_mode == RT_MODE_REST) { if (eligible) return; }
                 else if (!eligible) return;
