@@ -14,6 +14,7 @@
 #ifndef RT_AMD_H
 #define RT_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -139,6 +140,21 @@ int rt_probe_max_depth(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* pa
  * height*width*bytes_per_pixel.  Both device pointers on the context's GPU. */
 int rt_deinterleave_bands(rt_ctx* ctx, const void* gathered, void* frame_out, int32_t width, int32_t height,
                           int32_t bytes_per_pixel, int32_t band_rows, int32_t nranks, int32_t rows_per_rank);
+
+/* Tile streaming: replaces the producer side of the reference's Redis tile list (src/main.cpp:283-326 pushing through
+ * Redis::SendImage, src/redis.h:27-36).  The frame is rendered in chunks of whole tile rows; after each chunk every
+ * tile of it is handed to `sink` as the two records the reference pushes per tile, in this order:
+ *     [int32 tile_x][int32 tile_y][tile*tile x 3 bytes  of `pixel`]          8 + tile*tile*3  bytes
+ *     [int32 tile_x][int32 tile_y][tile*tile x 4 floats of `emissionPixel`]  8 + tile*tile*16 bytes
+ * (rows of a tile top to bottom, host byte order: exactly what Redis::ReceiveImage unpacks, redis.h:38-48).  Like the
+ * reference, only whole tiles are produced: width / tile columns and height / tile rows of tiles (src/main.cpp:276).
+ * Tiles arrive row by row, left to right (the reference's order depends on its thread pool).  `rows_per_chunk` is
+ * rounded down to whole tile rows (0: the whole frame in one chunk); progress = records delivered * 100 /
+ * (2 * tiles), the figure src/main.cpp:337 prints.  A non-zero return of `sink` stops the stream (RT_ERR_INVALID_ARG).
+ * params->row0 / rows / band_* are ignored: the call covers the frame. */
+typedef int (*rt_tile_sink)(void* user, const uint8_t* record, size_t bytes);
+int rt_render_tiles(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* params, int32_t tile, int32_t rows_per_chunk,
+                    rt_tile_sink sink, void* user);
 
 /* Durations in milliseconds of the last rt_render_rows, from HIP events on the context's stream: from the launch of
  * the direct kernel to the end of all render kernels of the call (direct, listed, heavy, resume: they overlap), and

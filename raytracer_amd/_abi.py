@@ -16,10 +16,14 @@ RT_FLAG_SINGLE_KERNEL = 4
 RT_FLAG_FORCE_SAMPLE_PARALLEL = 8
 
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_probe_max_depth",
+    "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_render_tiles", "rt_probe_max_depth",
     "rt_deinterleave_bands", "rt_last_kernel_ms", "rt_last_device_ms", "rt_last_hip_error", "rt_strerror",
     "rt_debug_rand", "rt_debug_quantise", "rt_debug_intersect",
 ]
+
+
+# rt_tile_sink: int (*)(void* user, const uint8_t* record, size_t bytes)
+TILE_SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_ubyte), ctypes.c_size_t)
 
 
 class SceneSoA(ctypes.Structure):
@@ -74,6 +78,7 @@ def load():
     lib.rt_camera_init.argtypes = [ctypes.POINTER(Camera35f)] + [ctypes.c_float] * 5
     lib.rt_render_rows.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), vp, vp, vp]
     lib.rt_probe_max_depth.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), vp]
+    lib.rt_render_tiles.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), i32, i32, TILE_SINK, vp]
     lib.rt_deinterleave_bands.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32]
     lib.rt_last_kernel_ms.argtypes = [vp]
     lib.rt_last_kernel_ms.restype = ctypes.c_float

@@ -58,6 +58,7 @@ struct rt_ctx {
 
     // pixel classes: keys (u16 per pixel) | pixel list (u32 per pixel) | histogram + cursor (2 * RT_MAX_KEYS u32)
     void* d_classes = nullptr; size_t classes_bytes = 0;
+    void* d_tiles = nullptr; size_t tiles_bytes = 0;   // rt_render_tiles: chunk rows + tile records
     void* d_heavy = nullptr; size_t heavy_bytes = 0;   // sample-parallel pixels: count | records | generator states
     bool any_bounce = false;             // some material has reflection > 0 or refraction > 0
 };
@@ -234,6 +235,7 @@ void rt_destroy(rt_ctx* ctx)
     if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
     if (ctx->d_classes) (void)hipFree(ctx->d_classes);
     if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
+    if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -497,6 +499,54 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     if (count) {
         counters->primary = (uint64_t)npix * (uint64_t)p->samples * 4u;
         counters->closest = words[0]; counters->shadow = words[1]; counters->tests = words[2]; counters->rand_draws = words[3]; counters->shaded = words[4];
+    }
+    return RT_OK;
+}
+
+int rt_render_tiles(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, int32_t tile, int32_t rows_per_chunk,
+                    rt_tile_sink sink, void* user)
+{
+    if (!ctx || !cam || !p || !sink) return RT_ERR_INVALID_ARG;
+    if (tile <= 0 || tile > 256 || rows_per_chunk < 0) return RT_ERR_INVALID_ARG;
+    rt_params q = *p;
+    q.row0 = 0; q.rows = p->height; q.band_rows = 0; q.band_stride = 0;
+    q.flags &= ~(RT_FLAG_COUNT_LIKE_REFERENCE | RT_FLAG_COUNT_EXECUTED);
+    int rc = check_params(ctx, cam, &q);
+    if (rc != RT_OK) return rc;
+    const int tiles_x = p->width / tile, tiles_y = p->height / tile;          // src/main.cpp:276: whole tiles only
+    if (tiles_x == 0 || tiles_y == 0) return RT_OK;
+    int chunk_tiles_y = rows_per_chunk == 0 ? tiles_y : rows_per_chunk / tile;
+    if (chunk_tiles_y < 1) chunk_tiles_y = 1;
+    if (chunk_tiles_y > tiles_y) chunk_tiles_y = tiles_y;
+
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    const size_t img_bytes = 8 + (size_t)tile * tile * 3, em_bytes = 8 + (size_t)tile * tile * 16;
+    const size_t chunk_rows = (size_t)chunk_tiles_y * tile, chunk_tiles = (size_t)chunk_tiles_y * tiles_x;
+    const size_t rgb_bytes = (chunk_rows * p->width * 3 + 15) & ~(size_t)15, emi_bytes = chunk_rows * p->width * 16;
+    const size_t irec_bytes = (chunk_tiles * img_bytes + 15) & ~(size_t)15, erec_bytes = chunk_tiles * em_bytes;
+    rc = grow(ctx, &ctx->d_tiles, &ctx->tiles_bytes, rgb_bytes + emi_bytes + irec_bytes + erec_bytes);
+    if (rc) return rc;
+    unsigned char* d_rgb = (unsigned char*)ctx->d_tiles;
+    unsigned char* d_emi = d_rgb + rgb_bytes;
+    unsigned char* d_irec = d_emi + emi_bytes;
+    unsigned char* d_erec = d_irec + irec_bytes;
+    std::vector<unsigned char> h_rec(irec_bytes + erec_bytes);
+
+    for (int ty0 = 0; ty0 < tiles_y; ty0 += chunk_tiles_y) {
+        const int nty = ty0 + chunk_tiles_y <= tiles_y ? chunk_tiles_y : tiles_y - ty0;
+        q.row0 = ty0 * tile; q.rows = nty * tile;
+        rc = rt_render_rows(ctx, cam, &q, d_rgb, (float*)d_emi, nullptr);
+        if (rc != RT_OK) return rc;
+        const int n = nty * tiles_x;
+        HIP_TRY(ctx, rt_launch_tile_pack(d_rgb, d_emi, p->width, tile, tiles_x, ty0, n, d_irec, d_erec, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h_rec.data(), d_irec, (size_t)n * img_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h_rec.data() + irec_bytes, d_erec, (size_t)n * em_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int t = 0; t < n; ++t) {                                         // src/main.cpp:325-326: image, then emission
+            if (sink(user, h_rec.data() + (size_t)t * img_bytes, img_bytes) != 0) return RT_ERR_INVALID_ARG;
+            if (sink(user, h_rec.data() + irec_bytes + (size_t)t * em_bytes, em_bytes) != 0) return RT_ERR_INVALID_ARG;
+        }
     }
     return RT_OK;
 }

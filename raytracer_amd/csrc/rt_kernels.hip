@@ -904,6 +904,40 @@ __global__ void deinterleave_kernel(const unsigned char* __restrict__ gathered, 
     }
 }
 
+// Tile records for a streaming consumer: what the reference's Redis::SendImage pushes per tile (redis.h:27-36 as called
+// from main.cpp:322-326): [int tile x][int tile y][tile*tile pixels], once with `pixel` (3 B) and once with
+// `emissionPixel` (16 B) payloads.  rgb / emission: `rows` packed rows of the frame starting at a tile boundary.
+// One thread per pixel of the covered tiles; record t of the chunk = tile (t % tiles_x, tile_y0 + t / tiles_x).
+__global__ __launch_bounds__(BLOCK) void tile_pack_kernel(const unsigned char* __restrict__ rgb, const float4* __restrict__ emission,
+                                                          int width, int tile, int tiles_x, int tile_y0, int n_tiles,
+                                                          unsigned char* __restrict__ img_rec, unsigned char* __restrict__ em_rec)
+{
+    const int per_tile = tile * tile;
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= (long long)n_tiles * per_tile) return;
+    const int t = (int)(i / per_tile), q = (int)(i % per_tile);
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    const int x = tx * tile + q % tile, r = ty * tile + q / tile;           // r: row within the chunk
+    const size_t src = (size_t)x + (size_t)r * width;
+    const size_t img_bytes = 8 + (size_t)per_tile * 3, em_bytes = 8 + (size_t)per_tile * 16;
+    unsigned char* ir = img_rec + (size_t)t * img_bytes;
+    unsigned char* er = em_rec + (size_t)t * em_bytes;
+    if (q == 0) {
+        // image records are 8 + 3*tile*tile bytes long: not a multiple of 4 for odd tiles, so the coordinates go in bytewise
+        const unsigned int cx = (unsigned int)tx, cy = (unsigned int)(tile_y0 + ty);
+        for (int b = 0; b < 4; ++b) { ir[b] = (unsigned char)(cx >> (8 * b)); ir[4 + b] = (unsigned char)(cy >> (8 * b)); }
+        int* ec = (int*)er; ec[0] = (int)cx; ec[1] = (int)cy;
+    }
+    ir[8 + (size_t)q * 3 + 0] = rgb[src * 3 + 0];
+    ir[8 + (size_t)q * 3 + 1] = rgb[src * 3 + 1];
+    ir[8 + (size_t)q * 3 + 2] = rgb[src * 3 + 2];
+    // emission records start 8 bytes into a 16-byte-aligned buffer: 8-byte stores
+    const float4 e = emission[src];
+    float2* ep = (float2*)(er + 8 + (size_t)q * 16);
+    ep[0] = make_float2(e.x, e.y);
+    ep[1] = make_float2(e.z, e.w);
+}
+
 // ---- unit-test kernels (rt_debug_*) -------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void debug_rand_kernel(const unsigned int* seeds, int n_seeds, int n_draws, int* out)
 {
@@ -1122,6 +1156,17 @@ hipError_t rt_launch_deinterleave(const void* gathered, void* frame, int row_byt
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(deinterleave_kernel, dim3(bx, height), dim3(256), 0, stream, (const unsigned char*)gathered,
                        (unsigned char*)frame, row_bytes, height, band_rows, nranks, rows_per_rank);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_tile_pack(const void* rgb, const void* emission, int width, int tile, int tiles_x, int tile_y0, int n_tiles,
+                               void* img_rec, void* em_rec, hipStream_t stream)
+{
+    const long long n = (long long)n_tiles * tile * tile;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_pack_kernel, dim3((unsigned int)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream,
+                       (const unsigned char*)rgb, (const float4*)emission, width, tile, tiles_x, tile_y0, n_tiles,
+                       (unsigned char*)img_rec, (unsigned char*)em_rec);
     return hipGetLastError();
 }
 

@@ -76,6 +76,8 @@ hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream
 hipError_t rt_launch_probe(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_deinterleave(const void* gathered, void* frame, int row_bytes, int height, int band_rows,
                                   int nranks, int rows_per_rank, hipStream_t stream);
+hipError_t rt_launch_tile_pack(const void* rgb, const void* emission, int width, int tile, int tiles_x, int tile_y0, int n_tiles,
+                               void* img_rec, void* em_rec, hipStream_t stream);
 hipError_t rt_launch_debug_rand(const unsigned int* seeds, int n_seeds, int n_draws, int* out, hipStream_t stream);
 hipError_t rt_launch_debug_quantise(const float* in, int n, unsigned char* out, hipStream_t stream);
 hipError_t rt_launch_debug_intersect(const float4* hrec, int index, const float* rays, int n, float* out8, hipStream_t stream);

@@ -4,7 +4,7 @@
 // / `new HittablesList` / `new DirectionalLight` / `new LightsList` calls, or an rtscene file.
 //
 //   rt_render [--scene file] [--w 1024 --h 512 --samples 5 --depth 10 --seed-base 0] [--out output.ppm]
-//             [--emission out.f32] [--probe] [--speedup]
+//             [--emission out.f32] [--probe] [--speedup] [--tiles 16 [--chunk-rows 128]]
 #include "../renderer.h"
 
 #include "../lights/directionalLight.h"
@@ -22,6 +22,7 @@ int main(int argc, char** argv)
     RenderSettings st;
     const char* scenePath = nullptr; const char* out = "output.ppm"; const char* outEm = nullptr;
     bool probe = false, speedup = false;
+    int tiles = 0, chunkRows = 0;
     for (int i = 1; i < argc; ++i) {
         auto is = [&](const char* k) { return !std::strcmp(argv[i], k) && i + 1 < argc; };
         if      (is("--scene"))     scenePath = argv[++i];
@@ -33,6 +34,8 @@ int main(int argc, char** argv)
         else if (is("--device"))    st.device = std::atoi(argv[++i]);
         else if (is("--out"))       out = argv[++i];
         else if (is("--emission"))  outEm = argv[++i];
+        else if (is("--tiles"))     tiles = std::atoi(argv[++i]);
+        else if (is("--chunk-rows")) chunkRows = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--probe"))   probe = true;
         else if (!std::strcmp(argv[i], "--speedup")) speedup = true;
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -76,6 +79,27 @@ int main(int argc, char** argv)
     } else if (speedup) {
         double ms = RenderTimed(camera, world, lights, materials, st);
         if (ms < 0) rc = 1; else std::printf("Ended in: %lf\n", ms);                       // src/tests/speedUp.cpp:48
+    } else if (tiles > 0) {
+        // the reference's producer / consumer pair around its Redis list (src/main.cpp:283-395), without the list: tiles
+        // arrive as SendImage arguments and are recomposed the way the RPOP loop does it
+        std::vector<pixel> image((size_t)st.width * st.height);
+        std::vector<emissionPixel> emission((size_t)st.width * st.height);
+        auto send = [&](const unsigned char* data, int sX, int sY, int w, int h, int elementSize) {
+            for (int nY = 0; nY < h; ++nY) {
+                const size_t dst = (size_t)sX * w + ((size_t)sY * h + nY) * st.width;
+                if (elementSize == (int)sizeof(pixel)) std::memcpy(&image[dst], data + (size_t)nY * w * elementSize, (size_t)w * elementSize);
+                else                                   std::memcpy(&emission[dst], data + (size_t)nY * w * elementSize, (size_t)w * elementSize);
+            }
+        };
+        auto progress = [](float percent) { std::printf("Progress: %f%%\n", percent); };           // src/main.cpp:337
+        auto t0 = std::chrono::steady_clock::now();
+        int status = RenderTiles(camera, world, lights, materials, materialsCount, st, tiles, chunkRows, send, progress);
+        std::printf("Ended in: %lf ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        if (status != RT_OK) { std::fprintf(stderr, "RenderTiles failed: %s\n", rt_strerror(status)); rc = 1; }
+        else {
+            writePPM(out, image.data(), st.width, st.height);
+            if (outEm) { FILE* f = std::fopen(outEm, "wb"); std::fwrite(emission.data(), sizeof(emissionPixel), emission.size(), f); std::fclose(f); }
+        }
     } else {
         std::vector<pixel> image((size_t)st.width * st.height);
         std::vector<emissionPixel> emission(outEm ? (size_t)st.width * st.height : 0);

@@ -110,6 +110,39 @@ inline int RenderImage(Camera& camera, Hittable* world, Light* lights, Material*
     return rc;
 }
 
+// The producer side of the reference's tile list (src/main.cpp:283-340): every whole tileSize x tileSize tile of the frame
+// is handed to `send` twice, with the arguments the reference gives Redis::SendImage (src/redis.h:27) -- first the
+// `pixel` payload, then the `emissionPixel` payload -- and `progress` (if set) receives the percentage the reference
+// prints (src/main.cpp:337) after every chunk of `rowsPerChunk` rows.  A consumer written against Redis::ReceiveImage
+// sees the same records.
+//   send(const unsigned char* image, int x, int y, int width, int height, int elementSize)
+template <class Send, class Progress>
+inline int RenderTiles(Camera& camera, Hittable* world, Light* lights, Material* materials, int materialsCount,
+                       const RenderSettings& settings, int tileSize, int rowsPerChunk, Send send, Progress progress)
+{
+    rt_host::Session s(world, lights, materials, materialsCount, settings.device);
+    if (s.status != RT_OK) return s.status;
+    rt_camera35f cam;
+    rt_host::camera35(camera, cam);
+    rt_params p = rt_host::params(settings);
+    struct State { Send* send; Progress* progress; int tile, delivered, total, per_chunk; } st;
+    st.send = &send; st.progress = &progress; st.tile = tileSize; st.delivered = 0;
+    st.total = 2 * (settings.width / tileSize) * (settings.height / tileSize);
+    const int chunk_tile_rows = rowsPerChunk <= 0 ? settings.height / tileSize : (rowsPerChunk / tileSize > 0 ? rowsPerChunk / tileSize : 1);
+    st.per_chunk = 2 * (settings.width / tileSize) * chunk_tile_rows;
+    rt_tile_sink sink = [](void* user, const uint8_t* record, size_t bytes) -> int {
+        State& t = *static_cast<State*>(user);
+        int x, y;
+        std::memcpy(&x, record, sizeof(int)); std::memcpy(&y, record + sizeof(int), sizeof(int));
+        const int elementSize = (int)((bytes - 2 * sizeof(int)) / ((size_t)t.tile * t.tile));
+        (*t.send)(record + 2 * sizeof(int), x, y, t.tile, t.tile, elementSize);
+        ++t.delivered;
+        if (t.delivered % t.per_chunk == 0 || t.delivered == t.total) (*t.progress)((float)(t.delivered * 100) / (float)t.total);
+        return 0;
+    };
+    return rt_render_tiles(s.ctx, &cam, &p, tileSize, rowsPerChunk, sink, &st);
+}
+
 // The reference's benchmark entry point (src/tests/speedUp.cpp:69-134): renders the frame, discards it, returns the
 // elapsed wall-clock milliseconds.  WIDTH / HEIGHT / SAMPLES / MAXDEPTH are compile-time macros of the including
 // file there; define them before including this header to get the same spelling, or use RenderTimed().  `threads`

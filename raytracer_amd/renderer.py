@@ -106,6 +106,25 @@ class Renderer:
         cnt = self.render_rows(cam, p, rgb, em, count=count)
         return rgb, em, cnt
 
+    def render_tiles(self, width, height, samples, max_depth, seed_base=0, tile=16, rows_per_chunk=0, sink=None, cam=None):
+        """rt_render_tiles: streams the frame as the reference's Redis tile records (src/redis.h:27-36).  `sink(record:
+        bytes)` is called per record (return a true value to stop); without a sink the records are collected.
+        -> list of records (bytes) when no sink was given"""
+        cam = cam or camera35f(self.scene, width, height)
+        p = self.params(width, height, samples, max_depth, seed_base)
+        got = []
+
+        def _sink(_user, rec, n):
+            data = ctypes.string_at(rec, n)
+            if sink is None:
+                got.append(data)
+                return 0
+            return 1 if sink(data) else 0
+
+        cb = _abi.TILE_SINK(_sink)
+        self._check(self._lib.rt_render_tiles(self._h, ctypes.byref(cam), ctypes.byref(p), tile, rows_per_chunk, cb, None), "rt_render_tiles")
+        return got if sink is None else None
+
     def probe_max_depth(self, width, height, max_depth, seed_base=0, cam=None):
         p = self.params(width, height, 1, max_depth, seed_base)
         cam = cam or camera35f(self.scene, width, height)

@@ -152,6 +152,40 @@ def test_capacity_and_sample_count_edges(rt):
             assert np.array_equal(got, want), (samples, flags)
 
 
+def test_tile_stream_matches_reference_records(rt):
+    """rt_render_tiles hands out what the reference pushes to its Redis list per 16x16 tile (src/main.cpp:322-326,
+    src/redis.h:27-36): [int x][int y][pixels] then [int x][int y][emissionPixels].  Reassembled like the reference's
+    consumer does (src/main.cpp:378-395), the records give the oracle's frame; partial tiles at the right / bottom edge
+    are not produced (src/main.cpp:276)."""
+    sc = scenes.glass_mirror()
+    W, H, samples, depth, seed, T = 150, 70, 2, 6, 3, 16
+    want, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, seed, threads=8)
+    rt.upload_scene(sc)
+    for rows_per_chunk in (0, 16, 40):
+        recs = rt.render_tiles(W, H, samples, depth, seed, tile=T, rows_per_chunk=rows_per_chunk)
+        tx, ty = W // T, H // T
+        assert len(recs) == 2 * tx * ty
+        img = np.zeros((ty * T, tx * T, 3), np.uint8)
+        em = np.zeros((ty * T, tx * T, 4), np.float32)
+        for k in range(0, len(recs), 2):
+            a, b = recs[k], recs[k + 1]
+            assert len(a) == 8 + T * T * 3 and len(b) == 8 + T * T * 16
+            x, y = np.frombuffer(a[:8], np.int32)
+            assert tuple(np.frombuffer(b[:8], np.int32)) == (x, y) and (x, y) == ((k // 2) % tx, (k // 2) // tx)
+            img[y * T:(y + 1) * T, x * T:(x + 1) * T] = np.frombuffer(a[8:], np.uint8).reshape(T, T, 3)
+            em[y * T:(y + 1) * T, x * T:(x + 1) * T] = np.frombuffer(b[8:], np.float32).reshape(T, T, 4)
+        assert np.array_equal(img, want[:ty * T, :tx * T])
+        assert np.array_equal(em.view(np.uint32), want_em[:ty * T, :tx * T].view(np.uint32))
+    # an odd tile size, and a sink that stops the stream
+    recs = rt.render_tiles(W, H, samples, depth, seed, tile=5)
+    assert len(recs) == 2 * (W // 5) * (H // 5) and np.array_equal(
+        np.frombuffer(recs[2][8:], np.uint8).reshape(5, 5, 3), want[0:5, 5:10])
+    seen = []
+    with pytest.raises(ra._abi.RtError):
+        rt.render_tiles(W, H, samples, depth, seed, tile=T, sink=lambda rec: seen.append(rec) or len(seen) >= 3)
+    assert len(seen) == 3
+
+
 def test_executed_tally_prunes_only_shadow_queries(rt):
     """RT_FLAG_COUNT_EXECUTED tallies the production kernel: same image, same closest-hit / draw counts, fewer (or
     equal) shadow queries and primitive tests than the reference issues."""

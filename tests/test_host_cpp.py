@@ -98,3 +98,19 @@ def test_cpp_driver_scene_file_and_probe(golden_dir):
         assert r.returncode == 0 and "Status: Failed!" in r.stdout      # some pixel reaches the cap in this scene
         r = subprocess.run([EXE, "--w", "128", "--h", "64", "--samples", "2", "--speedup"], capture_output=True, text=True)
         assert r.returncode == 0 and "Ended in:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_driver_tile_stream_recomposes_golden(golden_dir):
+    """--tiles: RenderTiles() hands tiles to a SendImage-shaped callback (src/redis.h:27), the driver recomposes them
+    like the reference's consumer loop (src/main.cpp:378-395) and prints the reference's progress line."""
+    z = np.load(os.path.join(golden_dir, "default4_256x128_s5_d10_seed1000.npz"))
+    with tempfile.TemporaryDirectory() as td:
+        out, em = os.path.join(td, "o.ppm"), os.path.join(td, "o.em")
+        r = subprocess.run([EXE, "--w", "256", "--h", "128", "--samples", "5", "--depth", "10", "--seed-base", "1000",
+                            "--tiles", "16", "--chunk-rows", "32", "--out", out, "--emission", em], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.array_equal(_read_ppm(out), z["rgb"])
+        assert np.array_equal(np.fromfile(em, dtype=np.uint32), z["emission"].view(np.uint32).ravel())
+        lines = [l for l in r.stdout.splitlines() if l.startswith("Progress:")]
+        assert len(lines) == 4 and lines[-1].startswith("Progress: 100.0")
