@@ -1,20 +1,24 @@
-// HIP kernels of the TraceRay hot path for gfx950 and their launchers.  See DESIGN.md for the execution model.
+// HIP kernels of the TraceRay hot path for gfx950 and their launchers.  DESIGN.md section 5 has the execution model.
 //
-// One thread owns one pixel (its RNG stream is strictly sequential: rand.h seeds per pixel, main.cpp:304).  A frame
-// is rendered by two kernels that run side by side (DESIGN.md "execution model"):
-//   direct_kernel  -- pixels none of whose four primary rays hits a reflective / refractive material: every ray is
-//                     closest hit + one shading, no RNG, no bounce stack, no scratch; 8x8-pixel waves, 16x16 tiles;
-//   render_kernel  -- the general per-pixel driver (iterative TraceRay with its stack in scratch) over the compacted,
-//                     material-sorted list of the remaining pixels, at raised wave priority.
-// classify_kernel decides which pixel goes where (one closest-hit query per primary direction), scan / scatter kernels
-// build the list.  Tallying builds (tests, bench ray counts) run render_kernel over every pixel instead.
+// One thread owns one pixel (its RNG stream is strictly sequential: rand.h seeds per pixel, main.cpp:304) unless noted.
+//   classify / scan / scatter -- which pixels can bounce (one closest-hit query per primary direction), compacted into
+//                     a material-grouped list;
+//   direct_kernel  -- all other pixels: every ray is closest hit + one shading, no RNG, no bounce stack, no scratch;
+//                     8x8-pixel waves, 16x16 tiles, per-wave candidate lists;
+//   render_kernel  -- the general per-pixel driver (iterative TraceRay with its stack in scratch): over the list, twice
+//                     (one launch owns the long pixels whose draw counts repeat and hands them over, one the rest), or
+//                     over every pixel for tallying builds and RT_FLAG_SINGLE_KERNEL;
+//   heavy_kernel   -- handed-over pixels, one wave per pixel, one lane per sample, draws read from the pixel's written-
+//                     out rand() stream at guessed indices; resume_kernel finishes what it gives up on;
+//   coop_kernel    -- listed pixels of large scenes, one wave per pixel, the lanes share every scan of the scene;
+//   tile_pack / deinterleave / probe / debug kernels.
 #include "rt_device.hpp"
 #include "rt_launch.h"
 
 namespace rt {
 
 constexpr int BLOCK = 256;
-// waves per SIMD the register allocator must leave room for (72 VGPRs at 7); measured in DESIGN.md "occupancy"
+// waves per SIMD the register allocator must leave room for in the tiled general kernel (72 VGPRs at 7)
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 7
 #endif
