@@ -54,6 +54,10 @@ struct SceneLds {
     kptr4 khrec, klights; // the same records in global memory, for wave-uniform (scalar) reads
     kptr4 kprim;          // per sphere (camera - centre, |camera - centre|^2 - r^2): primary rays share their origin
     const unsigned int* order; // hittable indices sorted by type (cooperative scans)
+    // coop_kernel: per-wave candidate lists for the pixel's primary rays and their shadow rays (LDS, ascending indices);
+    // a negative count means there is no list
+    const unsigned short* cl_prim; int cl_nprim;
+    const unsigned short* cl_occl; int cl_noccl;
 #ifdef RT_SCALAR_SCENE
     __device__ __forceinline__ float4 urec(int i) const { f32x4 v = khrec[i]; return make_float4(v.x, v.y, v.z, v.w); }
     __device__ __forceinline__ float4 ulight(int i) const { f32x4 v = klights[i]; return make_float4(v.x, v.y, v.z, v.w); }
@@ -646,6 +650,51 @@ __device__ __forceinline__ float light_intensity_listed(const SceneLds& sc, cons
         if (intens > intensity) {
             bool occluded = (type == L_DIR) ? any_hit_listed<HAS_NONSPHERE, false>(sc, wl, position, l, 0.0f)
                                             : any_hit_listed<HAS_NONSPHERE, true>(sc, wl, position, l, dist);
+            if (!occluded) intensity = intens;
+        }
+    }
+    return intensity;
+}
+
+// The same queries over a short list of hittable indices in LDS (coop_kernel's primary segment: every lane of the wave
+// holds the same ray and walks the same list, in list order, with the sequential replacement rule).
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ int closest_hit_ldslist(const SceneLds& sc, const unsigned short* list, int n, v3 ro, v3 rd, float& best)
+{
+    float fa = 4.0f * dot(rd, rd);
+    v3 inv = mk(0, 0, 0);
+    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    best = 3.402823466e+38f;
+    int bi = -1;
+    for (int j = 0; j < n; ++j) {
+        const int i = list[j];
+        float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+        float t;
+        if (hittable_hit<HAS_NONSPHERE, false>(r0, r1, ro, rd, fa, inv, t) && !(t >= best)) { best = t; bi = i; }
+    }
+    return bi;
+}
+
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ float light_intensity_ldslist(const SceneLds& sc, const unsigned short* list, int n, v3 position, v3 normal)
+{
+    float intensity = 0.085f;
+    for (int i = 0; i < sc.n_lights; ++i) {
+        int type; float dist;
+        v3 l = light_direction(sc, i, position, type, dist);
+        float d = dot(normal, l);
+        float intens = d > 0 ? d : 0;
+        if (intens > intensity) {
+            float fa = 4.0f * dot(l, l);
+            v3 inv = mk(0, 0, 0);
+            if (HAS_NONSPHERE) inv = mk(1.0f / l.x, 1.0f / l.y, 1.0f / l.z);
+            bool occluded = false;
+            for (int j = 0; j < n && !occluded; ++j) {
+                const int h = list[j];
+                float4 r0 = sc.hrec[2 * h], r1 = sc.hrec[2 * h + 1];
+                occluded = (type == L_DIR) ? occluder_hit<HAS_NONSPHERE, false, false, false>(r0, r1, position, l, fa, inv, 0.0f)
+                                           : occluder_hit<HAS_NONSPHERE, false, true, false>(r0, r1, position, l, fa, inv, dist);
+            }
             if (!occluded) intensity = intens;
         }
     }

@@ -87,8 +87,10 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
             if (COUNT) ++cnt.closest;
             float dist;
             int bi;
-            if (!HAS_NONSPHERE && primary && BATCH != RT_COOP) bi = closest_hit_primary<COUNT>(sc, rd, dist, cnt);
-            else                           bi = closest_hit<HAS_NONSPHERE, COUNT, BATCH>(sc, ro, rd, dist, cnt);
+            const bool listed_query = BATCH == RT_COOP && primary && sc.cl_nprim >= 0;      // coop_kernel's candidate lists
+            if (listed_query)                                  bi = closest_hit_ldslist<HAS_NONSPHERE>(sc, sc.cl_prim, sc.cl_nprim, ro, rd, dist);
+            else if (!HAS_NONSPHERE && primary && BATCH != RT_COOP) bi = closest_hit_primary<COUNT>(sc, rd, dist, cnt);
+            else                                               bi = closest_hit<HAS_NONSPHERE, COUNT, BATCH>(sc, ro, rd, dist, cnt);
             primary = false;
             if (bi < 0) {                                                        // renderer.h:40-50
                 maxDepth = depth;
@@ -100,7 +102,9 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
                 Hit h = hit_record(sc, bi, ro, rd, dist);
                 v3 offPosition = h.position + h.normal * 0.005f;                 // renderer.h:55
                 if (COUNT) ++cnt.shaded;
-                float intensity = light_intensity<HAS_NONSPHERE, COUNT, PRUNE, BATCH>(sc, offPosition, h.normal, cnt);
+                float intensity = (listed_query && sc.cl_noccl >= 0)
+                    ? light_intensity_ldslist<HAS_NONSPHERE>(sc, sc.cl_occl, sc.cl_noccl, offPosition, h.normal)
+                    : light_intensity<HAS_NONSPHERE, COUNT, PRUNE, BATCH>(sc, offPosition, h.normal, cnt);
                 mat = h.material;
                 const float* m = sc.mats + 10 * mat;
                 color = (mk(m[0], m[1], m[2]) * intensity) * mult;               // renderer.h:64
@@ -238,6 +242,7 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     sc.n_hit = a.n_hit; sc.n_lights = a.n_lights;
     sc.khrec = (kptr4)a.hrec; sc.klights = (kptr4)a.lights; sc.kprim = (kptr4)a.prim;
     sc.order = a.order;
+    sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
     __syncthreads();
 }
 
@@ -785,6 +790,7 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArg
 // same words with the same values), so a workgroup of COOP_WAVES waves needs little more than the staged scene and
 // two of them fit a CU next to a 2049-hittable scene.
 constexpr int COOP_WAVES = 8;
+constexpr int COOP_LIST = 64;     // entries of a wave's candidate list (more candidates: no list, every scan covers the scene)
 
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
 __global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
@@ -803,8 +809,77 @@ __global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
     Counters cnt = { 0, 0, 0, 0, 0 };
     float* dirs = lds_free + wave;                                           // word j of wave w at [j * COOP_WAVES + w]
     unsigned int* rng_lds = (unsigned int*)(lds_free + 12 * COOP_WAVES) + wave;
+    const int y = frame_row(a, r);
+
+    // The pixel's primary rays and the shadow rays of their hit points are the same for every sample (the argument of
+    // rt_device.hpp "wave-level candidate lists", for one pixel): one cooperative pass finds the hittables they hit /
+    // that occlude them, and the primary segment of every sample runs over those two lists instead of the scene.
+    unsigned short* lp = (unsigned short*)(lds_free + (12 + 32) * COOP_WAVES) + wave * (2 * COOP_LIST);
+    unsigned short* lo = lp + COOP_LIST;
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+    primary_directions<COOP_WAVES>(a, dirs, x, y);
+    int nprim = 0, noccl = 0;
+    bool fits = true;
+    for (int base = 0; base < sc.n_hit && fits; base += 64) {
+        const int i = base + lane;
+        bool any = false;
+        if (i < sc.n_hit) {
+            const float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                const v3 rd = mk(dirs[(3 * k + 0) * COOP_WAVES], dirs[(3 * k + 1) * COOP_WAVES], dirs[(3 * k + 2) * COOP_WAVES]);
+                const float fa = 4.0f * dot(rd, rd);
+                v3 inv = mk(0, 0, 0);
+                if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                float t;
+                any = any || hittable_hit<HAS_NONSPHERE, false>(r0, r1, origin, rd, fa, inv, t);
+            }
+        }
+        const unsigned long long m = __ballot(any);
+        const int add = __popcll(m);
+        if (nprim + add > COOP_LIST) fits = false;
+        else if (any) lp[nprim + __popcll(m & below)] = (unsigned short)i;           // ascending: list order = scene order
+        nprim += add;
+    }
+    if (fits) {
+#pragma unroll 1
+        for (int k = 0; k < 4 && fits; ++k) {
+            const v3 rd = mk(dirs[(3 * k + 0) * COOP_WAVES], dirs[(3 * k + 1) * COOP_WAVES], dirs[(3 * k + 2) * COOP_WAVES]);
+            float dist;
+            const int bi = closest_hit_ldslist<HAS_NONSPHERE>(sc, lp, nprim, origin, rd, dist);
+            if (bi < 0) continue;
+            const Hit h = hit_record(sc, bi, origin, rd, dist);
+            const v3 pos = h.position + h.normal * 0.005f;
+            for (int j = 0; j < sc.n_lights && fits; ++j) {
+                int type; float ldist;
+                const v3 l = light_direction(sc, j, pos, type, ldist);
+                const float fa = 4.0f * dot(l, l);
+                v3 inv = mk(0, 0, 0);
+                if (HAS_NONSPHERE) inv = mk(1.0f / l.x, 1.0f / l.y, 1.0f / l.z);
+                for (int base = 0; base < sc.n_hit && fits; base += 64) {
+                    const int i = base + lane;
+                    bool o = false;
+                    if (i < sc.n_hit) {
+                        const float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+                        o = (type == L_DIR) ? occluder_hit<HAS_NONSPHERE, false, false, false>(r0, r1, pos, l, fa, inv, 0.0f)
+                                            : occluder_hit<HAS_NONSPHERE, false, true, false>(r0, r1, pos, l, fa, inv, ldist);
+                        for (int e = 0; o && e < noccl; ++e) o = lo[e] != (unsigned short)i;   // already listed
+                    }
+                    const unsigned long long m = __ballot(o);
+                    const int add = __popcll(m);
+                    if (noccl + add > COOP_LIST) fits = false;
+                    else if (o) lo[noccl + __popcll(m & below)] = (unsigned short)i;
+                    noccl += add;
+                }
+            }
+        }
+    }
+    if (fits) { sc.cl_prim = lp; sc.cl_nprim = nprim; sc.cl_occl = lo; sc.cl_noccl = noccl; }
+
     render_pixel<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, true, RT_COOP, false, COOP_WAVES>(
-        a, sc, dirs, rng_lds, x, frame_row(a, r), r, cnt, (threadIdx.x & 63) == 0);
+        a, sc, dirs, rng_lds, x, y, r, cnt, lane == 0);
 }
 
 // resume_kernel: the serial pixel loop for what heavy_kernel gave up on, one lane per pixel, from the sample its record
@@ -971,7 +1046,7 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.order = nullptr;
+    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.order = nullptr; sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
     v3 ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     float4 r0 = hrec[2 * index], r1 = hrec[2 * index + 1];
     float fa = 4.0f * dot(rd, rd);
@@ -1101,7 +1176,7 @@ hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream
 static size_t coop_lds_bytes(int n_hit, int n_lights, int n_mat)
 {
     size_t nm = (size_t)((10 * n_mat + 3) & ~3);
-    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)(12 + 32) * COOP_WAVES * 4 + 16;
+    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)(12 + 32) * COOP_WAVES * 4 + (size_t)COOP_WAVES * 2 * COOP_LIST * 2 + 16;
 }
 
 bool rt_launch_coop_fits(int n_hit, int n_lights, int n_mat)
