@@ -8,6 +8,15 @@ device buffer, the bands are gathered to rank 0 (RCCL) and reassembled there.  N
 configuration, DEFAULT-4 at 3840x2160, 64 spp, max depth 10 (it fits one GPU).  The frame is fixed, so scaling is
 "strong".  Ray counts are exact: the counting build of the kernel tallies closest-hit queries for the same frame
 outside the timed region (they equal the reference's, tests/test_gpu_parity.py).
+
+Frames in flight.  A rank's share of a frame is bound by the latency of its longest pixels, not by throughput
+(3.3 ms for an eighth of the 4K frame whose arithmetic is worth 0.7 ms), so the K timed frames are
+rendered with up to --frames-in-flight (default 6, at every N) frames of a rank under way at once
+(raytracer_amd/pipeline.py: host threads with a context each; gathers in frame order).  Every frame is rendered,
+gathered and reassembled in full inside the timed region.  After it, three frames run one at a time:
+`frame_latency_ms` is the time of such a frame, and the roofline object prices the render kernels of such a frame
+(HIP events around them; with frames in flight the kernels of different frames overlap and a launch's duration says
+nothing), which is also what the rocprofv3 summaries under profiles/ hold (`--frames-in-flight 1`).
 """
 import argparse
 import json
@@ -15,6 +24,30 @@ import os
 import subprocess
 import sys
 import time
+
+# frames in flight need a hardware queue per stream that is busy at once (3 per context); the box's default of 4 makes
+# streams of different frames wait for each other.  Must be set before HIP starts.  (--frames-in-flight 1 leaves it.)
+def _frames_in_flight_arg(argv):
+    gpus, fif = 1, None
+    for i, a in enumerate(argv):
+        for name in ("--gpus", "--frames-in-flight"):
+            v = None
+            if a == name and i + 1 < len(argv):
+                v = argv[i + 1]
+            elif a.startswith(name + "="):
+                v = a.split("=", 1)[1]
+            if v is not None and v.lstrip("-").isdigit():
+                if name == "--gpus":
+                    gpus = int(v)
+                else:
+                    fif = int(v)
+    return fif if fif else DEFAULT_IN_FLIGHT
+
+
+DEFAULT_IN_FLIGHT = 6
+HW_QUEUES = "16"
+if _frames_in_flight_arg(sys.argv[1:]) > 1:
+    os.environ["GPU_MAX_HW_QUEUES"] = HW_QUEUES
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -93,8 +126,9 @@ def cpu_baseline(scene, W, H, samples, depth, count_rays, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames of one rank under way at once (default %d)" % DEFAULT_IN_FLIGHT)
     ap.add_argument("--workload", default="default4_4k_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra rt_params.flags for A/B runs (4 = RT_FLAG_SINGLE_KERNEL, 8 = RT_FLAG_FORCE_SAMPLE_PARALLEL)")
@@ -105,6 +139,7 @@ def main():
     import torch.distributed as dist
     import raytracer_amd as ra
     from raytracer_amd import bands
+    from raytracer_amd.pipeline import FramePipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -121,34 +156,57 @@ def main():
     scene_name, W, H, samples, depth = WORKLOADS[args.workload]
     scene = ra.scenes.BUILTIN[scene_name]()
     seed = 0
-    rt = ra.Renderer(local_rank)
-    rt.upload_scene(scene)
+    in_flight = max(1, min(_frames_in_flight_arg(sys.argv[1:]), max(args.steps, 1)))
+    rts = [ra.Renderer(local_rank) for _ in range(in_flight)]
+    for r in rts:
+        r.upload_scene(scene)
+    rt = rts[0]
     cam = ra.camera35f(scene, W, H)
     rpr = bands.rows_per_rank(H, BAND_ROWS, world)
     p = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank, flags=args.flags)
-    block = torch.zeros((rpr, W, 3), dtype=torch.uint8, device=dev)
+    blocks = [torch.zeros((rpr, W, 3), dtype=torch.uint8, device=dev) for _ in range(in_flight * (2 if in_flight > 1 else 1))]
+    block = blocks[0]
     torch.cuda.synchronize()        # the library renders on its own stream: the zero fill must have landed
+    kernel_ms, device_ms = [], []
 
-    def step():
-        rt.render_rows(cam, p, block)
-        return bands.gather_frame(block, H, BAND_ROWS, rt)
+    def render(worker, out, k):
+        rts[worker].render_rows(cam, p, out)
+        if worker == 0:
+            kernel_ms.append(rt.last_kernel_ms)
+            device_ms.append(rt.last_device_ms)
+
+    pipe = FramePipeline(render, blocks, H, BAND_ROWS, rt, workers=in_flight)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # warm-up: W frames one at a time, then every context once
+    solo = FramePipeline(render, blocks[:1], H, BAND_ROWS, rt, workers=1)
     for _ in range(args.warmup):
-        step()
+        solo.run(1)
+    if in_flight > 1:
+        pipe.run(in_flight)
     sync()
-    kernel_ms, device_ms = [], []
+    del kernel_ms[:], device_ms[:]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame = step()
-        kernel_ms.append(rt.last_kernel_ms)
-        device_ms.append(rt.last_device_ms)
+    frame = pipe.run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
+    # untimed: three frames one at a time -- the latency of a frame on its own and the durations of its kernels when
+    # they do not overlap with another frame's (what the roofline object prices)
+    latency_ms = []
+    if in_flight > 1:
+        del kernel_ms[:], device_ms[:]
+    for _ in range(3):
+        sync()
+        t1 = time.perf_counter()
+        solo.run(1)
+        sync()
+        latency_ms.append((time.perf_counter() - t1) * 1e3)
+    if in_flight == 1:                       # the timed frames themselves ran one at a time
+        del kernel_ms[args.steps:], device_ms[args.steps:]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -171,6 +229,7 @@ def main():
     keys = ("primary", "closest", "shadow", "tests", "rand_draws", "shaded")
     tv = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device=dev)
     local_flops = algorithmic_flops(cnt, scene, W * p.rows, samples)
+    # duration of one frame's render kernels when they do not overlap with another frame's
     lf = torch.tensor([local_flops, float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tv)
@@ -185,23 +244,29 @@ def main():
         rays = tot["closest"]                       # primary + secondary closest-hit queries (renderer.h:40)
         sec_per_step = elapsed / args.steps
         value = rays / sec_per_step / 1e6
+        whole_region = flops / sec_per_step / 1e12 / world     # lower bound: everything of a frame, host gaps included
         achieved = flops / (kms * 1e-3) / 1e12 / world       # per GPU: slowest rank's kernel time
+        basis = ("duration of the frame's render kernels (direct, listed, heavy: they overlap) from HIP events" +
+                 ("" if in_flight == 1 else ", measured on three frames run one at a time after the timed region (inside it "
+                  "the kernels of the %d frames in flight overlap)" % in_flight))
         line = {
             "metric": "Mrays/s (primary+secondary) at 4K/64spp; % FP32 VALU peak",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp": samples, "max_depth": depth,
-                       "seed_base": seed, "parallelism": "cyclic %d-row bands over %d GPU(s), RCCL gather to rank 0" % (BAND_ROWS, world)},
+                       "seed_base": seed, "parallelism": "cyclic %d-row bands over %d GPU(s), RCCL gather to rank 0" % (BAND_ROWS, world),
+                       "frames_in_flight": in_flight, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+            "frame_latency_ms": round(float(np.median(latency_ms)), 3),
             "rays": {"primary": tot["primary"], "secondary": tot["closest"] - tot["primary"], "shadow": tot["shadow"],
                      "primitive_tests": tot["tests"], "rng_draws": tot["rand_draws"],
                      "note": tally_note},
             "kernel_ms": round(kms, 3), "device_ms_rank0": round(float(np.mean(device_ms)), 3),
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "timed_region_frac": round(whole_region / PEAK_FP32_TFLOPS, 4),
                          "note": "algorithmic FP32 flops of the frame (SURVEY 8d table x the reference algorithm's query "
-                                 "tallies) / duration of the frame's render kernels (direct, listed, heavy: they overlap) "
-                                 "from HIP events. The kernels execute fewer flops than that: per-wave candidate lists "
+                                 "tallies) / " + basis + ". The kernels execute fewer flops than that: per-wave candidate lists "
                                  "and shadow-query pruning skip tests known to fail, so frac can pass the 0.5 that "
                                  "un-fused FP32 code could reach by brute force. Executed VALU issue utilisation per "
                                  "kernel (PMC counters) is in profiles/"},
@@ -213,7 +278,8 @@ def main():
                 return rt.render_rows(cam, ps, block[:n], count=True)["closest"]
             line["cpu_baseline"] = cpu_baseline(scene, W, H, samples, depth, count_rays)
         print(json.dumps(line), flush=True)
-    rt.close()
+    for r in rts:
+        r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

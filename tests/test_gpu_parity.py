@@ -296,6 +296,40 @@ def test_device_output_buffers_and_deinterleave(rt):
     assert np.array_equal(frame_em.cpu().numpy().view(np.uint32), full_em.view(np.uint32))
 
 
+def test_frames_in_flight_equal_frames_one_at_a_time(rt):
+    """raytracer_amd/pipeline.py: several contexts rendering different frames at once on one GPU, from host threads,
+    produce the bytes of the same frames rendered alone (glass: listed, sample-parallel and resume kernels overlap
+    across contexts)."""
+    import torch
+    from raytracer_amd import bands
+    from raytracer_amd.pipeline import FramePipeline
+    sc = scenes.glass_mirror()
+    W, H, samples, depth = 160, 96, 16, 12
+    band, in_flight, n_frames = 16, 3, 7
+    rt.upload_scene(sc)
+    want = [rt.render(W, H, samples, depth, seed_base=1000 * k)[0] for k in range(n_frames)]
+    cam = ra.camera35f(sc, W, H)
+    rts = [ra.Renderer(0) for _ in range(in_flight)]
+    try:
+        for r in rts:
+            r.upload_scene(sc)
+        blocks = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0") for _ in range(2 * in_flight)]
+        torch.cuda.synchronize()
+
+        def render(worker, block, k):
+            p = bands.band_params(rts[worker], W, H, samples, depth, 1000 * k, band, 1, 0)
+            rts[worker].render_rows(cam, p, block)
+
+        got = {}
+        FramePipeline(render, blocks, H, band, rts[0], workers=in_flight).run(n_frames, on_frame=lambda k, f: got.__setitem__(k, f.cpu().numpy()))
+    finally:
+        for r in rts:
+            r.close()
+    assert sorted(got) == list(range(n_frames))
+    for k in range(n_frames):
+        assert np.array_equal(got[k], want[k]), "frame %d" % k
+
+
 def test_probe_max_depth(rt, golden_dir):
     z = np.load(os.path.join(golden_dir, "probe_glass_mirror_128x64_d3_seed0.npz"))
     sc = scenes.Scene.from_text(bytes(z["scene"]).decode())

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Times a sequence of frames with F frames in flight (raytracer_amd/pipeline.py) on one GPU:
+    tools/pipeline_time.py <workload> <frames> <F> [<F> ...]        F = producers (contexts)
+RT_EMULATE_RANKS=N renders rank 0's share of an N-GPU frame (cyclic 16-row bands), i.e. what one rank of an N-GPU
+job does per frame minus the RCCL gather.  RT_HW_QUEUES sets GPU_MAX_HW_QUEUES before HIP starts."""
+import os
+import sys
+import time
+
+if os.environ.get("RT_HW_QUEUES"):
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["RT_HW_QUEUES"]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracer_amd as ra
+from raytracer_amd import bands
+from raytracer_amd.pipeline import FramePipeline
+from bench import WORKLOADS
+
+wl, frames = sys.argv[1], int(sys.argv[2])
+scene_name, W, H, samples, depth = WORKLOADS[wl]
+scene = ra.scenes.BUILTIN[scene_name]()
+ranks = int(os.environ.get("RT_EMULATE_RANKS", "1"))
+cam = ra.camera35f(scene, W, H)
+rpr = bands.rows_per_rank(H, 16, ranks)
+ref = None
+for F in [int(f) for f in sys.argv[3:]] or [1]:
+    rts = [ra.Renderer(0) for _ in range(F)]
+    for rt in rts:
+        rt.upload_scene(scene)
+    p = bands.band_params(rts[0], W, H, samples, depth, 0, 16, ranks, 0)
+    nblocks = F * int(os.environ.get("RT_BLOCKS_PER_WORKER", "2"))
+    blocks = [torch.zeros((rpr, W, 3), dtype=torch.uint8, device="cuda") for _ in range(nblocks)]
+    torch.cuda.synchronize()
+    pipe = FramePipeline(lambda w, block, k: rts[w].render_rows(cam, p, block), blocks, rpr, 16, rts[0], workers=F)
+    pipe.run(F)                                         # warm every context
+    for rep in range(2):
+        t0 = time.perf_counter()
+        last = pipe.run(frames)
+        dt = time.perf_counter() - t0
+        cs = int(last.sum(dtype=torch.int64))
+        ref = cs if ref is None else ref
+        print("%s ranks %d in-flight %d: %.3f ms/frame over %d frames, checksum %d%s" % (
+            wl, ranks, F, dt / frames * 1e3, frames, cs, "" if cs == ref else "  MISMATCH"), flush=True)
+    for rt in rts:
+        rt.close()
