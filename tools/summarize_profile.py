@@ -25,7 +25,7 @@ timed = [r for r in stats if "rt::" in r["Name"] and int(r["Calls"]) >= 2
 timed.sort(key=lambda r: (0 if "direct_kernel" in r["Name"] else 1, -float(r["TotalDurationNs"])))
 
 lines = ["# rocprofv3 summary `%s`" % tag, "", note, "",
-         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` and one "
+         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1` (frames one at a time: with frames in flight the kernels of different frames overlap and a launch's duration says nothing about it) and one "
          "`rocprofv3 --pmc ...` run per counter group (tools/profile_gpu.sh).  Under `--pmc` rocprofv3 serialises the "
          "dispatches, so the counters below are per kernel even though the kernels of a frame overlap in a normal run.", "",
          "## Kernel trace (`%s_kernel_stats.csv`)" % tag, "", "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
