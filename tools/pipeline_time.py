@@ -2,7 +2,8 @@
 """Times a sequence of frames with F frames in flight (raytracer_amd/pipeline.py) on one GPU:
     tools/pipeline_time.py <workload> <frames> <F> [<F> ...]        F = producers (contexts)
 RT_EMULATE_RANKS=N renders rank 0's share of an N-GPU frame (cyclic 16-row bands), i.e. what one rank of an N-GPU
-job does per frame minus the RCCL gather.  RT_HW_QUEUES sets GPU_MAX_HW_QUEUES before HIP starts."""
+job does per frame minus the RCCL gather.  RT_HW_QUEUES sets GPU_MAX_HW_QUEUES before HIP starts; RT_FLAGS = rt_params.flags
+(16 = RT_FLAG_DIRECT_FIRST)."""
 import os
 import sys
 import time
@@ -27,7 +28,7 @@ for F in [int(f) for f in sys.argv[3:]] or [1]:
     rts = [ra.Renderer(0) for _ in range(F)]
     for rt in rts:
         rt.upload_scene(scene)
-    p = bands.band_params(rts[0], W, H, samples, depth, 0, 16, ranks, 0)
+    p = bands.band_params(rts[0], W, H, samples, depth, 0, 16, ranks, 0, flags=int(os.environ.get("RT_FLAGS", "0")))
     nblocks = F * int(os.environ.get("RT_BLOCKS_PER_WORKER", "2"))
     blocks = [torch.zeros((rpr, W, 3), dtype=torch.uint8, device="cuda") for _ in range(nblocks)]
     torch.cuda.synchronize()
