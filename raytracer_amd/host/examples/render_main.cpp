@@ -5,6 +5,7 @@
 //
 //   rt_render [--scene file] [--w 1024 --h 512 --samples 5 --depth 10 --seed-base 0] [--out output.ppm]
 //             [--emission out.f32] [--probe] [--speedup] [--tiles 16 [--chunk-rows 128]]
+//             [--frames 8 [--in-flight 4]]      frame k is seeded seed-base + 1000 k and written to <out>.<k>.ppm
 #include "../renderer.h"
 
 #include "../lights/directionalLight.h"
@@ -22,7 +23,7 @@ int main(int argc, char** argv)
     RenderSettings st;
     const char* scenePath = nullptr; const char* out = "output.ppm"; const char* outEm = nullptr;
     bool probe = false, speedup = false;
-    int tiles = 0, chunkRows = 0;
+    int tiles = 0, chunkRows = 0, frames = 0, inFlight = 4;
     for (int i = 1; i < argc; ++i) {
         auto is = [&](const char* k) { return !std::strcmp(argv[i], k) && i + 1 < argc; };
         if      (is("--scene"))     scenePath = argv[++i];
@@ -36,6 +37,8 @@ int main(int argc, char** argv)
         else if (is("--emission"))  outEm = argv[++i];
         else if (is("--tiles"))     tiles = std::atoi(argv[++i]);
         else if (is("--chunk-rows")) chunkRows = std::atoi(argv[++i]);
+        else if (is("--frames"))    frames = std::atoi(argv[++i]);
+        else if (is("--in-flight")) inFlight = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--probe"))   probe = true;
         else if (!std::strcmp(argv[i], "--speedup")) speedup = true;
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -79,6 +82,21 @@ int main(int argc, char** argv)
     } else if (speedup) {
         double ms = RenderTimed(camera, world, lights, materials, st);
         if (ms < 0) rc = 1; else std::printf("Ended in: %lf\n", ms);                       // src/tests/speedUp.cpp:48
+    } else if (frames > 0) {
+        // a sequence of frames, several in flight; delivered in order
+        auto t0 = std::chrono::steady_clock::now();
+        int delivered = 0;
+        int status = RenderFrames(camera, world, lights, materials, materialsCount, st, frames, inFlight,
+                                  [&](int k) { return st.seedBase + 1000LL * k; },
+                                  [&](int k, const pixel* image) {
+                                      if (k != delivered++) std::fprintf(stderr, "frame %d out of order\n", k);
+                                      char path[1024];
+                                      std::snprintf(path, sizeof path, "%s.%d.ppm", out, k);
+                                      writePPM(path, image, st.width, st.height);
+                                  });
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (status != RT_OK) { std::fprintf(stderr, "RenderFrames failed: %s\n", rt_strerror(status)); rc = 1; }
+        else std::printf("Ended in: %lf ms, %lf ms per frame (%d frames, %d in flight)\n", ms, ms / frames, frames, inFlight);
     } else if (tiles > 0) {
         // the reference's producer / consumer pair around its Redis list (src/main.cpp:283-395), without the list: tiles
         // arrive as SendImage arguments and are recomposed the way the RPOP loop does it

@@ -10,6 +10,8 @@
 //   Render()           = double Render(Camera&, Hittable*, Light*, Material*, int threads) of
 //                        src/tests/speedUp.cpp:26,69 (same signature, returns elapsed ms, discards the pixels)
 //   MaxRayDistanceAny()= the per-pixel MaxRayDistance sweep of src/tests/singlePixel.cpp:65-120
+//   RenderFrames()     = a sequence of frames with several under way at once: the reference's producer / consumer
+//                        shape (src/main.cpp:268-331 workers, :375-395 consumer) applied to whole frames
 //
 // Errors: the reference signals none on this path; these functions return the rt_status of the failing C-ABI call
 // (RenderImage, MaxRayDistanceAny) or a negative time (Render), and never fall back to the CPU.
@@ -25,8 +27,13 @@
 #include "rt_amd.h"
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 struct RenderSettings
 {
@@ -141,6 +148,84 @@ inline int RenderTiles(Camera& camera, Hittable* world, Light* lights, Material*
         return 0;
     };
     return rt_render_tiles(s.ctx, &cam, &p, tileSize, rowsPerChunk, sink, &st);
+}
+
+// A sequence of `frames` frames with up to `inFlight` of them under way on the GPU at once.  One frame on its own is
+// bound by the latency of its longest pixels (a pixel's samples are serial through its generator, src/main.cpp:304-318)
+// while most of the GPU idles; a sequence hides that (the glass 1080p / 64 spp frame takes 169 ms
+// alone and 50 ms per frame with six in flight).  `inFlight` producer threads, each with a context of its own, take
+// frame numbers in order and render into a ring of 2 * inFlight host images; the calling thread hands the images out in
+// frame order:
+//   seedOf(k)           -> long long: frame k's seed base (what time(NULL) is to one run of the reference, rand.h:7);
+//                          called from the producer threads
+//   deliver(k, image)   called on the calling thread, frames in order; `image` (width*height pixels) is reused after
+//                          the call returns
+// Every frame's bytes are those of RenderImage() with settings.seedBase = seedOf(k).  Set GPU_MAX_HW_QUEUES=16 in the
+// environment before the first HIP call of the process.  Returns the first failing rt_status.
+template <class SeedOf, class Deliver>
+inline int RenderFrames(Camera& camera, Hittable* world, Light* lights, Material* materials, int materialsCount,
+                        const RenderSettings& settings, int frames, int inFlight, SeedOf seedOf, Deliver deliver)
+{
+    if (frames <= 0) return RT_OK;
+    const int F = inFlight < 1 ? 1 : (inFlight > frames ? frames : inFlight);
+    const int B = 2 * F;
+    std::vector<std::unique_ptr<rt_host::Session>> sessions;
+    for (int w = 0; w < F; ++w) {
+        sessions.emplace_back(new rt_host::Session(world, lights, materials, materialsCount, settings.device));
+        if (sessions.back()->status != RT_OK) return sessions.back()->status;
+    }
+    rt_camera35f cam;
+    rt_host::camera35(camera, cam);
+    const size_t npix = (size_t)settings.width * settings.height;
+    std::vector<std::vector<pixel>> images(B, std::vector<pixel>(npix));
+    enum { FREE, BUSY, READY };
+    std::vector<int> state(B, FREE);
+    std::mutex m;
+    std::condition_variable cv;
+    int next = 0, status = RT_OK;
+
+    auto producer = [&](int w) {
+        for (;;) {
+            int k, b;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                k = next++;                                  // frames are taken in order; frame k lives in image k % B,
+                if (k >= frames) return;                     // which is free once frame k - B was delivered
+                b = k % B;
+                cv.wait(lock, [&] { return state[b] == FREE || status != RT_OK; });
+                if (status != RT_OK) return;
+                state[b] = BUSY;
+            }
+            rt_params p = rt_host::params(settings);
+            p.seed_base = seedOf(k);
+            const int rc = rt_render_rows(sessions[w]->ctx, &cam, &p, reinterpret_cast<uint8_t*>(images[b].data()), nullptr, nullptr);
+            {
+                std::lock_guard<std::mutex> lock(m);
+                if (rc != RT_OK && status == RT_OK) status = rc;
+                state[b] = READY;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int w = 0; w < F; ++w) threads.emplace_back(producer, w);
+    for (int k = 0; k < frames; ++k) {
+        const int b = k % B;
+        {
+            std::unique_lock<std::mutex> lock(m);
+            cv.wait(lock, [&] { return state[b] == READY || status != RT_OK; });
+            if (status != RT_OK) break;
+        }
+        deliver(k, images[b].data());
+        {
+            std::lock_guard<std::mutex> lock(m);
+            state[b] = FREE;
+        }
+        cv.notify_all();
+    }
+    cv.notify_all();                            // after a failure: producers waiting for an image leave
+    for (auto& t : threads) t.join();
+    return status;
 }
 
 // The reference's benchmark entry point (src/tests/speedUp.cpp:69-134): renders the frame, discards it, returns the

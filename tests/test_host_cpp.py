@@ -114,3 +114,24 @@ def test_cpp_driver_tile_stream_recomposes_golden(golden_dir):
         assert np.array_equal(np.fromfile(em, dtype=np.uint32), z["emission"].view(np.uint32).ravel())
         lines = [l for l in r.stdout.splitlines() if l.startswith("Progress:")]
         assert len(lines) == 4 and lines[-1].startswith("Progress: 100.0")
+
+
+@pytest.mark.gpu
+def test_cpp_driver_frames_in_flight(golden_dir):
+    """--frames: RenderFrames() keeps several frames under way (one context per producer thread) and delivers them in
+    order; frame 1 of a sequence seeded 0, 1000, 2000, ... is the golden seed-1000 frame, and every frame equals the
+    same frame rendered alone."""
+    z = np.load(os.path.join(golden_dir, "default4_256x128_s5_d10_seed1000.npz"))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "seq")
+        r = subprocess.run([EXE, "--w", "256", "--h", "128", "--samples", "5", "--depth", "10", "--seed-base", "0",
+                            "--frames", "7", "--in-flight", "3", "--out", out], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "out of order" not in r.stderr, r.stdout + r.stderr
+        assert np.array_equal(_read_ppm(out + ".1.ppm"), z["rgb"])
+        for k in (0, 4, 6):
+            alone = os.path.join(td, "alone.ppm")
+            r = subprocess.run([EXE, "--w", "256", "--h", "128", "--samples", "5", "--depth", "10", "--seed-base", str(1000 * k),
+                                "--out", alone], capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert np.array_equal(_read_ppm(out + ".%d.ppm" % k), _read_ppm(alone)), k
