@@ -45,6 +45,7 @@ struct rt_ctx {
     const float4* d_hrec = nullptr; const float4* d_lights = nullptr; const float* d_mats = nullptr;
     float4* d_prim = nullptr;                    // camera-relative sphere terms, refreshed when the camera moves
     const unsigned int* d_order = nullptr;       // hittable indices sorted by type (cooperative scans)
+    const unsigned int* d_slot_of = nullptr;     // the inverse: place of every hittable in that order
     std::vector<float> h_centres_r2;             // host copy of (centre, r^2) per hittable
     float prim_cam[3] = { 0, 0, 0 }; bool prim_valid = false;
 
@@ -136,12 +137,14 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
     a.n_hit = ctx->n_hit; a.n_lights = ctx->n_lights; a.n_mat = ctx->n_mat;
     a.hrec = ctx->d_hrec; a.lights = ctx->d_lights; a.mats = ctx->d_mats;
     a.rgb = nullptr; a.emission = nullptr; a.counters = ctx->d_counters; a.fault = ctx->d_fault;
+    a.queue = (unsigned int*)(ctx->d_fault + 1);         // the word after it: reset with the counters
     a.keys = nullptr; a.hist = nullptr; a.list = nullptr; a.list_count = 0; a.list_count_dev = nullptr;
     a.fallback_count = nullptr; a.fallback_list = nullptr; a.listed_mode = 0;
     a.heavy_count = nullptr; a.heavy_rec = nullptr; a.heavy_pool = nullptr; a.heavy_pool_used = nullptr;
     a.heavy_pool_words = 0; a.heavy_cap = 0; a.heavy_min_work = 0;
     a.prim = ctx->d_prim;
     a.order = ctx->d_order;
+    a.slot_of = ctx->d_slot_of;
 }
 
 // Primary rays all start at the camera: origin - centre and dot(origin, origin) - r*r (sphere.h:15,19) are per-sphere
@@ -275,8 +278,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     }
 
     const int nh = s->n_hittables, nl = s->n_lights, nm = s->n_materials;
-    // hrec | lights | mats (padded to 4 floats) | prim (filled per camera) | type-sorted order of the hittables
-    std::vector<float> img((size_t)nh * 8 + (size_t)nl * 4 + (size_t)nm * 10 + 4 + (size_t)nh * 4 + (size_t)nh, 0.0f);
+    // hrec | lights | mats (padded to 4 floats) | prim (filled per camera) | type-sorted order of the hittables | its inverse
+    std::vector<float> img((size_t)nh * 8 + (size_t)nl * 4 + (size_t)nm * 10 + 4 + (size_t)nh * 4 + 2 * (size_t)nh, 0.0f);
     float* hrec = img.data();
     float* lights = hrec + (size_t)nh * 8;
     float* mats = lights + (size_t)nl * 4;
@@ -330,6 +333,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
             for (int i = 0; i < nh; ++i)
                 if (s->h_type[i] == type) order.push_back((uint32_t)i);
         if (nh > 0) std::memcpy(&img[prim_at + (size_t)nh * 4], order.data(), sizeof(uint32_t) * (size_t)nh);
+        // ... and slot_of[hittable] = its place in that order (the sequential fallback walks the scene in scene order)
+        std::vector<uint32_t> slot_of((size_t)nh);
+        for (int j = 0; j < nh; ++j) slot_of[order[(size_t)j]] = (uint32_t)j;
+        if (nh > 0) std::memcpy(&img[prim_at + (size_t)nh * 5], slot_of.data(), sizeof(uint32_t) * (size_t)nh);
     }
 
     if (rt_launch_lds_bytes(nh, nl, nm) > 160 * 1024) return RT_ERR_UNSUPPORTED;
@@ -350,6 +357,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     ctx->d_mats = (const float*)ctx->d_scene + (size_t)nh * 8 + (size_t)nl * 4;
     ctx->d_prim = (float4*)((float*)ctx->d_scene + prim_at);
     ctx->d_order = (const unsigned int*)((const float*)ctx->d_scene + prim_at + (size_t)nh * 4);
+    ctx->d_slot_of = ctx->d_order + nh;
     ctx->h_centres_r2.resize((size_t)nh * 4);
     for (int i = 0; i < nh; ++i) std::memcpy(&ctx->h_centres_r2[4 * (size_t)i], hrec + 8 * (size_t)i, 16);
     ctx->prim_valid = false;

@@ -53,7 +53,11 @@ struct SceneLds {
     int n_hit, n_lights;
     kptr4 khrec, klights; // the same records in global memory, for wave-uniform (scalar) reads
     kptr4 kprim;          // per sphere (camera - centre, |camera - centre|^2 - r^2): primary rays share their origin
-    const unsigned int* order; // hittable indices sorted by type (cooperative scans)
+    // coop_kernel stages the records sorted by type: hrec[2 * slot], and every index it handles is a slot.  orig (LDS):
+    // slot -> index in the scene, which decides ties; slot_of (global): the inverse, for walking in scene order.  Both
+    // null when the order is the scene's own (sphere-only scenes, every other kernel).
+    const unsigned short* orig;
+    const unsigned int* slot_of;
     // coop_kernel: per-wave candidate lists for the pixel's primary rays and their shadow rays (LDS, ascending indices);
     // a negative count means there is no list
     const unsigned short* cl_prim; int cl_nprim;
@@ -352,6 +356,7 @@ template <bool HAS_NONSPHERE>
 __device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd, float& best)
 {
     const int lane = (int)(threadIdx.x & 63);
+    const bool sorted = HAS_NONSPHERE && sc.orig != nullptr;
     float fa = 4.0f * dot(rd, rd);
     v3 inv = mk(0, 0, 0);
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
@@ -359,22 +364,24 @@ __device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd
     int bi = -1;
     bool nan_seen = false;
     for (int j = lane; j < sc.n_hit; j += 64) {
-        const int i = HAS_NONSPHERE ? (int)sc.order[j] : j;
-        float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+        float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
         float t;
         if (hittable_hit<HAS_NONSPHERE, false>(r0, r1, ro, rd, fa, inv, t)) {
             nan_seen = nan_seen || (t != t);
-            if (!(t >= best)) { best = t; bi = i; }
+            // slots ascend, scene indices need not: equal distances go to the lower scene index
+            if (!(t >= best) || (sorted && t == best && bi >= 0 && sc.orig[j] < sc.orig[bi])) { best = t; bi = j; }
         }
     }
     if (__ballot(nan_seen) != 0ull) return closest_hit_seq<HAS_NONSPHERE>(sc, ro, rd, best);
+    int bo = (sorted && bi >= 0) ? (int)sc.orig[bi] : bi;      // the winner's index in the scene
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
         float ot = __shfl_xor(best, m);
-        int oi = __shfl_xor(bi, m);
+        int oo = __shfl_xor(bo, m);
+        int oi = sorted ? __shfl_xor(bi, m) : oo;
         // no-hit lanes carry (FLT_MAX, -1): any hit is below FLT_MAX, two hits at the same distance go to the lower index
-        bool take = ot < best || (ot == best && oi >= 0 && (bi < 0 || oi < bi));
-        if (take) { best = ot; bi = oi; }
+        bool take = ot < best || (ot == best && oo >= 0 && (bo < 0 || oo < bo));
+        if (take) { best = ot; bo = oo; bi = oi; }
     }
     return bi;
 }
@@ -391,8 +398,7 @@ __device__ __forceinline__ bool any_hit_coop(const SceneLds& sc, v3 ro, v3 rd, f
         const int j = base + lane;
         bool o = false;
         if (j < sc.n_hit) {
-            const int i = HAS_NONSPHERE ? (int)sc.order[j] : j;
-            float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
+            float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
             o = occluder_hit<HAS_NONSPHERE, false, LIMITED, false>(r0, r1, ro, rd, fa, inv, limit);
         }
         if (__ballot(o) != 0ull) return true;
@@ -438,11 +444,22 @@ __device__ __forceinline__ int closest_hit(const SceneLds& sc, v3 ro, v3 rd, flo
     return bi;
 }
 
+// the sequential rule over the staged records, in scene order (the cooperative query's fallback when a distance is NaN)
 template <bool HAS_NONSPHERE>
 __device__ __forceinline__ int closest_hit_seq(const SceneLds& sc, v3 ro, v3 rd, float& best)
 {
-    Counters none = { 0, 0, 0, 0, 0 };
-    return closest_hit<HAS_NONSPHERE, false, 1>(sc, ro, rd, best, none);
+    float fa = 4.0f * dot(rd, rd);
+    v3 inv = mk(0, 0, 0);
+    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    best = 3.402823466e+38f;
+    int bi = -1;
+    for (int k = 0; k < sc.n_hit; ++k) {
+        const int j = (HAS_NONSPHERE && sc.slot_of) ? (int)sc.slot_of[k] : k;
+        float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
+        float t;
+        if (hittable_hit<HAS_NONSPHERE, false>(r0, r1, ro, rd, fa, inv, t) && !(t >= best)) { best = t; bi = j; }
+    }
+    return bi;
 }
 
 // The same query for a primary ray of a sphere-only scene: all primary rays start at the camera, so
@@ -657,7 +674,7 @@ __device__ __forceinline__ float light_intensity_listed(const SceneLds& sc, cons
 }
 
 // The same queries over a short list of hittable indices in LDS (coop_kernel's primary segment: every lane of the wave
-// holds the same ray and walks the same list, in list order, with the sequential replacement rule).
+// holds the same ray and walks the same list, in list order -- scene order --, with the sequential replacement rule).
 template <bool HAS_NONSPHERE>
 __device__ __forceinline__ int closest_hit_ldslist(const SceneLds& sc, const unsigned short* list, int n, v3 ro, v3 rd, float& best)
 {

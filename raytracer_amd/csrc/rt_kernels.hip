@@ -241,8 +241,30 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     sc.hrec = l_hrec; sc.lights = l_lights; sc.mats = l_mats;
     sc.n_hit = a.n_hit; sc.n_lights = a.n_lights;
     sc.khrec = (kptr4)a.hrec; sc.klights = (kptr4)a.lights; sc.kprim = (kptr4)a.prim;
-    sc.order = a.order;
+    sc.orig = nullptr; sc.slot_of = nullptr;
     sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
+    __syncthreads();
+}
+
+// coop_kernel's staging: the hittables sorted by type (a.order), so that lane l of a cooperative scan reads slot
+// base + l and the 64 tests of a round mostly take one branch; l_orig[slot] = index in the scene.  Sphere-only scenes
+// are in that order already.
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ void stage_scene_sorted(const KernelArgs& a, float4* lds, SceneLds& sc, float*& lds_free)
+{
+    stage_scene(a, lds, sc, lds_free);
+    if (!HAS_NONSPHERE) return;
+    float4* l_hrec = lds;
+    unsigned short* l_orig = (unsigned short*)lds_free;
+    const int nthreads = (int)blockDim.x;
+    __syncthreads();                                   // (stage_scene's copy is replaced: nobody reads it in between)
+    for (int j = threadIdx.x; j < a.n_hit; j += nthreads) {
+        const unsigned int i = a.order[j];
+        l_hrec[2 * j] = a.hrec[2 * i]; l_hrec[2 * j + 1] = a.hrec[2 * i + 1];
+        l_orig[j] = (unsigned short)i;
+    }
+    lds_free += (((size_t)a.n_hit * 2 + 15) & ~(size_t)15) / 4;
+    sc.orig = l_orig; sc.slot_of = a.slot_of;
     __syncthreads();
 }
 
@@ -798,25 +820,33 @@ __global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
     extern __shared__ float4 lds[];
     SceneLds sc;
     float* lds_free;
-    stage_scene(a, lds, sc, lds_free);
+    stage_scene_sorted<HAS_NONSPHERE>(a, lds, sc, lds_free);
     __builtin_amdgcn_s_setprio(3);
 
     const int wave = (int)(threadIdx.x >> 6);
-    const unsigned int i = blockIdx.x * COOP_WAVES + wave;
-    if (i >= (unsigned int)a.list_count) return;
-    const unsigned int o = a.list[i];
-    const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
+    const int lane = (int)(threadIdx.x & 63);
     Counters cnt = { 0, 0, 0, 0, 0 };
     float* dirs = lds_free + wave;                                           // word j of wave w at [j * COOP_WAVES + w]
     unsigned int* rng_lds = (unsigned int*)(lds_free + 12 * COOP_WAVES) + wave;
+    // Pixels differ in cost by orders of magnitude, and a workgroup holds its copy of the scene until its last wave is
+    // done: every wave therefore takes pixels from a queue (a counter over the list) until the list is used up, and
+    // the grid is only as large as fits the GPU at once (rt_launch_coop).
+    // (a wave takes at most list_count pixels: the bound is never reached, and no wave can spin for ever)
+    for (unsigned int turn = 0; turn <= (unsigned int)a.list_count; ++turn) {
+    unsigned int i = 0;
+    if (lane == 0) i = atomicAdd(a.queue, 1u);
+    i = (unsigned int)__builtin_amdgcn_readfirstlane((int)i);
+    if (i >= (unsigned int)a.list_count) break;
+    const unsigned int o = a.list[i];
+    const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
     const int y = frame_row(a, r);
+    sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
 
     // The pixel's primary rays and the shadow rays of their hit points are the same for every sample (the argument of
     // rt_device.hpp "wave-level candidate lists", for one pixel): one cooperative pass finds the hittables they hit /
     // that occlude them, and the primary segment of every sample runs over those two lists instead of the scene.
     unsigned short* lp = (unsigned short*)(lds_free + (12 + 32) * COOP_WAVES) + wave * (2 * COOP_LIST);
     unsigned short* lo = lp + COOP_LIST;
-    const int lane = (int)(threadIdx.x & 63);
     const unsigned long long below = (1ull << lane) - 1ull;
     const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
     primary_directions<COOP_WAVES>(a, dirs, x, y);
@@ -840,8 +870,21 @@ __global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
         const unsigned long long m = __ballot(any);
         const int add = __popcll(m);
         if (nprim + add > COOP_LIST) fits = false;
-        else if (any) lp[nprim + __popcll(m & below)] = (unsigned short)i;           // ascending: list order = scene order
+        else if (any) lp[nprim + __popcll(m & below)] = (unsigned short)i;           // ascending slots
         nprim += add;
+    }
+    if (HAS_NONSPHERE && fits && nprim > 1) {
+        // closest-hit queries walk this list with the sequential rule: it has to be in scene order, not slot order
+        unsigned short slot = 0;
+        int rank = 0;
+        if (lane < nprim) {
+            slot = lp[lane];
+            const unsigned short mine = sc.orig[slot];
+            for (int f = 0; f < nprim; ++f) rank += sc.orig[lp[f]] < mine;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nprim) lp[rank] = slot;
+        __builtin_amdgcn_wave_barrier();
     }
     if (fits) {
 #pragma unroll 1
@@ -880,6 +923,7 @@ __global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
 
     render_pixel<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, true, RT_COOP, false, COOP_WAVES>(
         a, sc, dirs, rng_lds, x, y, r, cnt, lane == 0);
+    }
 }
 
 // resume_kernel: the serial pixel loop for what heavy_kernel gave up on, one lane per pixel, from the sample its record
@@ -1046,7 +1090,7 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.order = nullptr; sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
+    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.orig = nullptr; sc.slot_of = nullptr; sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
     v3 ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     float4 r0 = hrec[2 * index], r1 = hrec[2 * index + 1];
     float fa = 4.0f * dot(rd, rd);
@@ -1175,8 +1219,10 @@ hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream
 
 static size_t coop_lds_bytes(int n_hit, int n_lights, int n_mat)
 {
+    // (+ the slot -> scene index table of stage_scene_sorted)
     size_t nm = (size_t)((10 * n_mat + 3) & ~3);
-    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)(12 + 32) * COOP_WAVES * 4 + (size_t)COOP_WAVES * 2 * COOP_LIST * 2 + 16;
+    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (((size_t)n_hit * 2 + 15) & ~(size_t)15)
+         + (size_t)(12 + 32) * COOP_WAVES * 4 + (size_t)COOP_WAVES * 2 * COOP_LIST * 2 + 16;
 }
 
 bool rt_launch_coop_fits(int n_hit, int n_lights, int n_mat)
@@ -1192,6 +1238,14 @@ static hipError_t launch_coop(K k, const KernelArgs& a, int blocks, size_t lds_b
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
+    // as many workgroups as are resident at once: their waves take pixels from the queue until it is empty
+    int per_cu = 0, dev = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, COOP_WAVES * 64, lds_bytes);
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    const int resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    if (blocks > resident) blocks = resident;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(COOP_WAVES * 64), lds_bytes, stream, a);
     return hipGetLastError();
 }

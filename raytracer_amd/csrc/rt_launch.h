@@ -32,11 +32,13 @@ struct KernelArgs {
     const float4* lights;        // n_lights
     const float* mats;           // 10 * n_mat
     const float4* prim;          // n_hit: per sphere (camera - centre, |camera - centre|^2 - r^2) for primary rays
-    const unsigned int* order;   // n_hit: hittable indices sorted by type, the order cooperative scans deal them to lanes
+    const unsigned int* order;   // n_hit: hittable indices sorted by type, the order coop_kernel stages them in
+    const unsigned int* slot_of; // n_hit: the inverse (place of hittable i in `order`)
     unsigned char* rgb;          // rows * width * 3 (probe: width * height flags)
     float4* emission;            // rows * width, or null
     unsigned long long* counters;// 5 words (closest, shadow, tests, draws, shaded), or null
     int* fault;                  // set to 1 by a kernel whose bounce stack would overflow
+    unsigned int* queue;         // coop_kernel: next entry of the pixel list to hand out (zero at launch)
     unsigned short* keys;        // rows * width pixel classes (0 = direct, 1 + material = general), or null
     unsigned int* hist;          // RT_MAX_KEYS pixel counts per key
     const unsigned int* list;    // pixel list of the listed render_kernel (indices into the packed output)

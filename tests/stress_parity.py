@@ -4,6 +4,8 @@ row selections over every built-in scene, the HIP path through the C-ABI against
 
     python tests/stress_parity.py [seconds=300] [seed=0]        RT_STRESS_BIG=1: larger frames at 16-64 spp (the long
                                                                   pixels of glass scenes reach the hand-over threshold)
+                                                                RT_STRESS_LARGE=1: only scenes of 257-900 hittables
+                                                                  (the cooperative route), more pixels than waves fit
 """
 import os
 import sys
@@ -23,6 +25,8 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 builders = [scenes.default4, scenes.random10, scenes.glass_mirror, scenes.plane_scene, scenes.cube_scene,
             scenes.point_light_scene, scenes.degenerate_scene, scenes.nan_scene,
             lambda: scenes.many_objects(n=300, n_lights=4, seed=int(rs.randint(1, 1000)))]
+if os.environ.get("RT_STRESS_LARGE"):
+    builders = [lambda: scenes.many_objects(n=int(rs.randint(257, 900)), n_lights=int(rs.randint(1, 9)), seed=int(rs.randint(1, 1000)))]
 rt = ra.Renderer(0)
 t_end = time.time() + budget
 n_cases = n_pixels = 0
@@ -33,6 +37,8 @@ while time.time() < t_end:
     depth = int(rs.choice([0, 1, 2, 5, 10, 12, 20, 64]))
     if len(sc.hittables) > 100:            # keep the oracle's share of the budget small
         W, H, samples, depth = min(W, 96), min(H, 64), min(samples, 8), min(depth, 10)
+        if os.environ.get("RT_STRESS_LARGE"):
+            W, H, samples = int(rs.randint(64, 200)), int(rs.randint(40, 120)), int(rs.choice([1, 2, 3]))
     pixel_samples = 3.0e6
     if os.environ.get("RT_STRESS_BIG") and len(sc.hittables) <= 100:
         W, H, samples = int(rs.randint(300, 1300)), int(rs.randint(200, 700)), int(rs.choice([16, 32, 64]))

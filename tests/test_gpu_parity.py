@@ -129,6 +129,52 @@ def test_large_scene_cooperative_route(rt):
     assert np.array_equal(rgb, want_rgb) and np.array_equal(em.view(np.uint32), want_em.view(np.uint32))
 
 
+def test_large_scene_more_pixels_than_resident_waves(rt):
+    """coop_kernel's grid is only as large as fits the GPU at once; its waves take pixels from a queue until the list is
+    used up.  A frame with several times more bounce pixels than resident waves (16 384 at most: 4 workgroups of 8
+    waves on each of 256 CUs, times two for headroom) makes every wave render many pixels."""
+    sc = scenes.many_objects(n=300, n_lights=2, seed=23)
+    W, H, samples, depth, seed = 800, 450, 1, 3, 6
+    want_rgb, _, _ = oracle_lib.render(sc, W, H, samples, depth, seed, threads=8, want_emission=False)
+    rt.upload_scene(sc)
+    rgb, _, _ = rt.render(W, H, samples, depth, seed)
+    assert np.array_equal(rgb, want_rgb)
+
+
+def test_large_scene_ties_across_types_go_to_the_lower_scene_index(rt):
+    """coop_kernel stages the hittables sorted by type, but equal distances must still go to the hittable that comes
+    first in the scene (hittablesList.h:25-27).  A cube early in the scene whose front face lies in a plane that comes
+    later (and the other way round), different materials, seen directly and through mirrors: plane and cube compute
+    the distance differently, and for a good share of the rays the two floats are equal."""
+    for first in ("cube", "plane"):
+        sc = scenes.Scene(name="ties_" + first)
+        scenes._default_materials(sc)
+        mirror = sc.material((0.9, 0.9, 0.9), 0.0, 0.9, 0.0)
+        rough = sc.material((0.2, 0.9, 0.3), 0.3, 0.6, 0.0)
+        sc.sphere((0.0, -1000.0, -4.0), 1000.0, 0)
+        def cube(): sc.cube((-4.0, 0.0, -9.0), (8.0, 5.0, 2.0), mirror)            # front face z = -7
+        def plane(): sc.plane((0.0, 0.0, -7.0), (0.0, 0.0, 1.0), rough)
+        (cube if first == "cube" else plane)()
+        sc.sphere((-2.0, 1.0, -2.0), 1.0, mirror)
+        sc.sphere((2.5, 1.2, -3.0), 1.2, 3)
+        rs = np.random.RandomState(5)
+        for k in range(270):                                                       # >= 256 hittables: cooperative route
+            x, z, r = rs.uniform(-30, 30), rs.uniform(-60, -12), rs.uniform(0.2, 0.6)
+            if k % 3 == 2:
+                sc.cube((x, 0.0, z), (r, r, r), k % 4)
+            else:
+                sc.sphere((x, r, z), r, k % 4)
+        (plane if first == "cube" else cube)()
+        sc.dirlight((-0.25, -0.75, 0.45))
+        sc.pointlight((6.0, 9.0, 2.0))
+        W, H, samples, depth, seed = 160, 90, 3, 6, 2
+        want_rgb, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, seed, threads=8)
+        rt.upload_scene(sc)
+        rgb, em, _ = rt.render(W, H, samples, depth, seed, emission=True)
+        assert np.array_equal(rgb, want_rgb), first
+        assert np.array_equal(em.view(np.uint32), want_em.view(np.uint32)), first
+
+
 def test_capacity_and_sample_count_edges(rt):
     """RT_MAX_HITTABLES hittables: the staged scene leaves no LDS for the generators, so the listed kernels keep them in
     scratch and neither the sample-parallel nor the cooperative route applies.  More than 64 samples per pixel (one
