@@ -20,12 +20,14 @@ shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(d
 
 # the timed kernels = rt:: kernels launched once per step (the tally build runs once); dominant = largest total time
 timed = [r for r in stats if "rt::" in r["Name"] and int(r["Calls"]) >= 2
-         and any(k in r["Name"] for k in ("render_kernel", "direct_kernel", "heavy_kernel", "classify_kernel"))]
-# the direct kernel carries ~80 % of a frame's VALU instructions: it leads; then by total time
-timed.sort(key=lambda r: (0 if "direct_kernel" in r["Name"] else 1, -float(r["TotalDurationNs"])))
+         and any(k in r["Name"] for k in ("render_kernel", "direct_kernel", "heavy_kernel", "classify_kernel", "coop_kernel"))]
+# the direct kernel carries ~80 % of a frame's VALU instructions: it leads (large scenes: the cooperative kernel
+# does); then by total time
+lead = "coop_kernel" if any("coop_kernel" in r["Name"] for r in timed) else "direct_kernel"
+timed.sort(key=lambda r: (0 if lead in r["Name"] else 1, -float(r["TotalDurationNs"])))
 
 lines = ["# rocprofv3 summary `%s`" % tag, "", note, "",
-         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1` (frames one at a time: with frames in flight the kernels of different frames overlap and a launch's duration says nothing about it) and one "
+         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline " + os.environ.get("RT_PROFILE_ARGS", "--frames-in-flight 1") + "` (frames one at a time: with frames in flight the kernels of different frames overlap and a launch's duration says nothing about it) and one "
          "`rocprofv3 --pmc ...` run per counter group (tools/profile_gpu.sh).  Under `--pmc` rocprofv3 serialises the "
          "dispatches, so the counters below are per kernel even though the kernels of a frame overlap in a normal run.", "",
          "## Kernel trace (`%s_kernel_stats.csv`)" % tag, "", "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
