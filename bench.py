@@ -148,10 +148,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    # rehearsal knobs for a one-GPU box (RCCL refuses two ranks on one device): RT_BENCH_DEVICE pins every rank to one
+    # device, RT_BENCH_BACKEND=gloo swaps the transport; the control flow -- pipeline, gather order, reductions -- is
+    # the one the N-GPU job runs
+    if os.environ.get("RT_BENCH_DEVICE"):
+        local_rank = int(os.environ["RT_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     scene_name, W, H, samples, depth = WORKLOADS[args.workload]
     scene = ra.scenes.BUILTIN[scene_name]()
