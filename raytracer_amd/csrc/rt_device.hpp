@@ -538,6 +538,54 @@ __device__ __forceinline__ bool any_hit(const SceneLds& sc, v3 ro, v3 rd, float 
     return false;
 }
 
+// LightsList::GetLightIntensity for the cooperative kernel.  Its value is max(0.085, the largest Lambert term among the
+// lights in sight) (lightsList.h:22-40): it does not depend on the order in which the lights are asked.  All lanes of
+// the wave hold the same point, so lane j works out light j's direction and Lambert term (the same float operations),
+// and the lights are asked for occlusion -- each a scan of the scene -- in descending order of their terms: the first
+// one in sight ends it, no later one can raise the maximum.  (At most 64 lights, RT_MAX_LIGHTS.)
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ float light_intensity_coop(const SceneLds& sc, v3 position, v3 normal)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    float my = -1.0f, lx = 0.0f, ly = 0.0f, lz = 0.0f, ldist = 0.0f;
+    int ltype = L_DIR;
+    if (lane < sc.n_lights) {
+        float4 L = sc.lights[lane];
+        ltype = __float_as_int(L.w);
+        v3 l;
+        if (ltype == L_DIR) {
+            l = mk(L.x, L.y, L.z);
+        } else {
+            v3 dv = mk(L.x, L.y, L.z) - position;
+            ldist = sqrtf(dot(dv, dv));
+            l = normalize(dv);
+        }
+        float d = dot(normal, l);
+        my = d > 0 ? d : 0;
+        lx = l.x; ly = l.y; lz = l.z;
+    }
+    float intensity = 0.085f;
+    for (int turn = 0; turn < sc.n_lights; ++turn) {
+        float best = my > intensity ? my : -1.0f;
+        int who = lane;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            float ob = __shfl_xor(best, m);
+            int ow = __shfl_xor(who, m);
+            if (ob > best || (ob == best && ow < who)) { best = ob; who = ow; }
+        }
+        if (!(best > intensity)) break;                      // no light left that could raise it
+        const v3 l = mk(__shfl(lx, who), __shfl(ly, who), __shfl(lz, who));
+        const int type = __shfl(ltype, who);
+        const float dist = __shfl(ldist, who);
+        const bool occluded = (type == L_DIR) ? any_hit_coop<HAS_NONSPHERE, false>(sc, position, l, 0.0f)
+                                              : any_hit_coop<HAS_NONSPHERE, true>(sc, position, l, dist);
+        if (!occluded) { intensity = best; break; }
+        if (lane == who) my = -1.0f;
+    }
+    return intensity;
+}
+
 // LightsList::GetLightIntensity (lightsList.h:22-40) over DirectionalLight (directionalLight.h:11-20) and the
 // repo-defined point light.  The reference asks IsInLight first and the Lambert term second; the result only
 // changes when the Lambert term exceeds the running maximum, so with PRUNE the occlusion query is skipped whenever
@@ -546,6 +594,7 @@ __device__ __forceinline__ bool any_hit(const SceneLds& sc, v3 ro, v3 rd, float 
 template <bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int BATCH = 1>
 __device__ __forceinline__ float light_intensity(const SceneLds& sc, v3 position, v3 normal, Counters& cnt)
 {
+    if (BATCH == RT_COOP && PRUNE && !COUNT) return light_intensity_coop<HAS_NONSPHERE>(sc, position, normal);
     float intensity = 0.085f;
     for (int i = 0; i < sc.n_lights; ++i) {
         float4 L = sc.ulight(i);
