@@ -3,7 +3,7 @@
     tools/pipeline_time.py <workload> <frames> <F> [<F> ...]        F = producers (contexts)
 RT_EMULATE_RANKS=N renders rank 0's share of an N-GPU frame (cyclic 16-row bands), i.e. what one rank of an N-GPU
 job does per frame minus the RCCL gather.  RT_HW_QUEUES sets GPU_MAX_HW_QUEUES before HIP starts; RT_FLAGS = rt_params.flags
-(16 = RT_FLAG_DIRECT_FIRST)."""
+(include/rt_amd.h) for A/B runs."""
 import os
 import sys
 import time
