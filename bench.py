@@ -172,7 +172,8 @@ def main():
     rt = rts[0]
     cam = ra.camera35f(scene, W, H)
     rpr = bands.rows_per_rank(H, BAND_ROWS, world)
-    p = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank, flags=args.flags)
+    seq = ra._abi.RT_FLAG_SEQUENCE if in_flight > 1 else 0          # several frames in flight on this GPU
+    p = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank, flags=args.flags | seq)
     blocks = [torch.zeros((rpr, W, 3), dtype=torch.uint8, device=dev) for _ in range(in_flight * (2 if in_flight > 1 else 1))]
     block = blocks[0]
     torch.cuda.synchronize()        # the library renders on its own stream: the zero fill must have landed

@@ -19,6 +19,10 @@
 #ifndef RT_COOP_MIN_HIT
 #define RT_COOP_MIN_HIT 256
 #endif
+// direct pixels x samples from which a frame on its own is taken to be bound by the direct kernel (see rng_scratch)
+#ifndef RT_DIRECT_BOUND_WORK
+#define RT_DIRECT_BOUND_WORK 2.5e8
+#endif
 #ifndef RT_HEAVY_TABLE_BYTES
 #define RT_HEAVY_TABLE_BYTES ((size_t)512 << 20)
 #endif
@@ -403,6 +407,7 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     t.nonsphere = ctx->nonsphere;
     t.count = count;
     t.listed = false;
+    t.rng_scratch = false;
     t.prune = (p->flags & RT_FLAG_COUNT_LIKE_REFERENCE) == 0;
     // frames on the bounce stack <= reflection parents (max_depth) + refraction parents (66)
     t.deep = refraction_chain_bound() + p->max_depth > RT_STACK_SHALLOW || p->max_depth > RT_PEND_SHALLOW - 1;
@@ -440,6 +445,13 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                 g2.list = list; g2.list_count = (int)n_listed;
                 LaunchTraits tg = t;
                 tg.listed = true;
+                // Where the listed kernel keeps its generators (31 words per pixel).  In LDS a lone wave is ~5 % faster,
+                // which is what a frame bound by its longest pixels wants; in scratch a listed workgroup holds 12 KB of
+                // LDS instead of 44 KB, which is what the direct kernel's workgroups want when the frame is bound by
+                // them (4K / 64 spp: 5.83 -> 5.73 ms) and what a sequence of frames wants (6 in flight: 4K frame 5.59 ->
+                // 5.39 ms, glass 1080p 65 -> 51 ms per frame; measured A/B on one box).
+                const double direct_work = (double)(npix - n_listed) * (double)p->samples;
+                tg.rng_scratch = (p->flags & RT_FLAG_SEQUENCE) != 0 || direct_work >= RT_DIRECT_BOUND_WORK;
                 // Long pixels leave the listed kernel after their first sample and are finished one wave per pixel,
                 // one lane per sample, by the heavy kernel behind it (DESIGN.md "sample-parallel pixels").
                 const bool force = (p->flags & RT_FLAG_FORCE_SAMPLE_PARALLEL) != 0;

@@ -1150,7 +1150,7 @@ hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStrea
     const int blocks = t.listed ? (a.list_count + BLOCK - 1) / BLOCK : a.tiles_x * a.tiles_y;
     size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
     // large scenes leave no room for the generators next to the staged records: they stay in scratch then
-    const bool lds_rng = t.listed && RT_LISTED_LDS_RNG && listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat) <= 160 * 1024;
+    const bool lds_rng = t.listed && RT_LISTED_LDS_RNG && listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat) <= 160 * 1024 && !t.rng_scratch;
     if (lds_rng) lds = listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
     // the tally builds are the most general ones: emission, mixed, all primitive types, deep stack
     if (t.count && !t.prune) return launch_with_lds(render_kernel<false, false, true, true, true, true, false, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream);

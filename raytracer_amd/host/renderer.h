@@ -198,6 +198,7 @@ inline int RenderFrames(Camera& camera, Hittable* world, Light* lights, Material
             }
             rt_params p = rt_host::params(settings);
             p.seed_base = seedOf(k);
+            if (F > 1) p.flags |= RT_FLAG_SEQUENCE;
             const int rc = rt_render_rows(sessions[w]->ctx, &cam, &p, reinterpret_cast<uint8_t*>(images[b].data()), nullptr, nullptr);
             {
                 std::lock_guard<std::mutex> lock(m);

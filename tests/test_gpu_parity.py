@@ -342,12 +342,28 @@ def test_device_output_buffers_and_deinterleave(rt):
     assert np.array_equal(frame_em.cpu().numpy().view(np.uint32), full_em.view(np.uint32))
 
 
+@pytest.mark.parametrize("name,W,H,samples,depth", [("default4", 333, 77, 8, 10), ("glass_mirror", 200, 120, 16, 12), ("cube", 96, 64, 3, 5)])
+def test_sequence_hint_gives_the_same_bytes(rt, name, W, H, samples, depth):
+    """RT_FLAG_SEQUENCE only moves the listed kernels' generators from LDS to scratch"""
+    from raytracer_amd import _abi
+    sc = scenes.BUILTIN[name]()
+    rt.upload_scene(sc)
+    cam = ra.camera35f(sc, W, H)
+    out = []
+    for flags in (0, _abi.RT_FLAG_SEQUENCE, _abi.RT_FLAG_SEQUENCE | _abi.RT_FLAG_FORCE_SAMPLE_PARALLEL):
+        rgb = np.zeros((H, W, 3), np.uint8); em = np.zeros((H, W, 4), np.float32)
+        rt.render_rows(cam, rt.params(W, H, samples, depth, 11, flags=flags), rgb, em)
+        out.append((rgb, em))
+    for rgb, em in out[1:]:
+        assert np.array_equal(rgb, out[0][0]) and np.array_equal(em.view(np.uint32), out[0][1].view(np.uint32))
+
+
 def test_frames_in_flight_equal_frames_one_at_a_time(rt):
     """raytracer_amd/pipeline.py: several contexts rendering different frames at once on one GPU, from host threads,
     produce the bytes of the same frames rendered alone (glass: listed, sample-parallel and resume kernels overlap
     across contexts)."""
     import torch
-    from raytracer_amd import bands
+    from raytracer_amd import _abi, bands
     from raytracer_amd.pipeline import FramePipeline
     sc = scenes.glass_mirror()
     W, H, samples, depth = 160, 96, 16, 12
@@ -363,7 +379,7 @@ def test_frames_in_flight_equal_frames_one_at_a_time(rt):
         torch.cuda.synchronize()
 
         def render(worker, block, k):
-            p = bands.band_params(rts[worker], W, H, samples, depth, 1000 * k, band, 1, 0)
+            p = bands.band_params(rts[worker], W, H, samples, depth, 1000 * k, band, 1, 0, flags=_abi.RT_FLAG_SEQUENCE if k % 2 else 0)
             rts[worker].render_rows(cam, p, block)
 
         got = {}

@@ -28,7 +28,7 @@ for F in [int(f) for f in sys.argv[3:]] or [1]:
     rts = [ra.Renderer(0) for _ in range(F)]
     for rt in rts:
         rt.upload_scene(scene)
-    p = bands.band_params(rts[0], W, H, samples, depth, 0, 16, ranks, 0, flags=int(os.environ.get("RT_FLAGS", "0")))
+    p = bands.band_params(rts[0], W, H, samples, depth, 0, 16, ranks, 0, flags=int(os.environ.get("RT_FLAGS", str(ra._abi.RT_FLAG_SEQUENCE if F > 1 else 0))))
     nblocks = F * int(os.environ.get("RT_BLOCKS_PER_WORKER", "2"))
     blocks = [torch.zeros((rpr, W, 3), dtype=torch.uint8, device="cuda") for _ in range(nblocks)]
     torch.cuda.synchronize()
