@@ -797,12 +797,19 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArg
     float* lds_free;
     stage_scene(a, lds, sc, lds_free);
     __builtin_amdgcn_s_setprio(3);
-    const unsigned int h = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    if (h >= count) return;
     // samples a round must settle on average: 2 while the pixels fit on the GPU at once, more when they queue
     int need_rate = (int)(count / 512u);
     need_rate = need_rate < 2 ? 2 : need_rate > 16 ? 16 : need_rate;
-    heavy_pixel<EMISSION, MIXED, HAS_NONSPHERE, MAXSP, MAXPEND>(a, sc, lds_free, h, need_rate);
+    // The grid is no larger than fits the GPU at once (rt_launch_heavy) -- the table's capacity is the length of the
+    // pixel list, the count usually a small part of it -- and every wave takes records from a queue until they are
+    // used up (a wave takes at most `count` of them: the bound is never reached, and no wave can spin).
+    for (unsigned int turn = 0; turn <= count; ++turn) {
+        unsigned int h = 0;
+        if ((threadIdx.x & 63) == 0) h = atomicAdd(a.queue, 1u);
+        h = (unsigned int)__builtin_amdgcn_readfirstlane((int)h);
+        if (h >= count) break;
+        heavy_pixel<EMISSION, MIXED, HAS_NONSPHERE, MAXSP, MAXPEND>(a, sc, lds_free, h, need_rate);
+    }
 }
 
 // coop_kernel: large scenes.  One wave per listed pixel; all 64 lanes run the pixel's path code on the same values and
@@ -1200,9 +1207,17 @@ bool rt_launch_heavy_fits(int n_hit, int n_lights, int n_mat)
 // the count the listed kernel left in a.heavy_count leave at once.  Then resume_kernel for what it gave up on.
 hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
 {
-    const int blocks = (a.heavy_cap + BLOCK / 64 - 1) / (BLOCK / 64);
+    int blocks = (a.heavy_cap + BLOCK / 64 - 1) / (BLOCK / 64);
     const int rblocks = (a.heavy_cap + BLOCK - 1) / BLOCK;
     const size_t lds = listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+    // heavy_kernel's waves take records from a queue: no more workgroups than are resident at once (44 KB of LDS each)
+    int dev = 0, cus = 0;
+    hipError_t q = hipGetDevice(&dev);
+    if (q == hipSuccess) q = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (q != hipSuccess) return q;
+    const int per_cu = (int)((size_t)160 * 1024 / (lds > 0 ? lds : 1));
+    const int resident = (per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu) * (cus > 0 ? cus : 1);
+    if (blocks > resident) blocks = resident;
 #define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N) {                                  \
         hipError_t e = t.deep ? launch_with_lds(heavy_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream)       \
                               : launch_with_lds(heavy_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, stream); \
