@@ -70,6 +70,12 @@ struct rt_ctx {
 
 // device words: 5 tallies (u64) followed by the fault flag
 #define RT_DEV_WORDS_BYTES (5 * sizeof(unsigned long long) + sizeof(int) * 2)
+// Everything a frame needs zeroed sits in one block behind them, so that one fill per frame does it (under load every
+// small dispatch waits its turn for tens of microseconds): the sample-parallel route's counters (heavy_count,
+// fallback_count, pool words used: 16 bytes), then the pixel classes' histogram and cursor (2 * RT_MAX_KEYS words).
+#define RT_DEV_HEAVY_AT  RT_DEV_WORDS_BYTES
+#define RT_DEV_HIST_AT   (RT_DEV_HEAVY_AT + 16)
+#define RT_DEV_STATE_BYTES (RT_DEV_HIST_AT + 2 * RT_MAX_KEYS * sizeof(unsigned int))
 
 #define HIP_TRY(ctx, expr)                                   \
     do {                                                     \
@@ -216,7 +222,7 @@ int rt_create(rt_ctx** out, int device_ordinal)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gen, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_rest, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, RT_DEV_WORDS_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, RT_DEV_STATE_BYTES);
     if (e != hipSuccess) { rt_destroy(ctx); return RT_ERR_HIP; }
     ctx->d_fault = (int*)(ctx->d_counters + 5);
     *out = ctx;
@@ -412,7 +418,7 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     // frames on the bounce stack <= reflection parents (max_depth) + refraction parents (66)
     t.deep = refraction_chain_bound() + p->max_depth > RT_STACK_SHALLOW || p->max_depth > RT_PEND_SHALLOW - 1;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_DEV_WORDS_BYTES, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_DEV_STATE_BYTES, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (count || (p->flags & RT_FLAG_SINGLE_KERNEL)) {
         // tallying builds and the A/B flag: the general kernel over every pixel
@@ -431,9 +437,8 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
             if (rc) return rc;
             a.keys = (unsigned short*)ctx->d_classes;
             unsigned int* list = (unsigned int*)((char*)ctx->d_classes + keys_bytes);
-            a.hist = list + npix;
+            a.hist = (unsigned int*)((char*)ctx->d_counters + RT_DEV_HIST_AT);        // zeroed with the counters
             unsigned int* cursor = a.hist + RT_MAX_KEYS;
-            HIP_TRY(ctx, hipMemsetAsync(a.hist, 0, 2 * RT_MAX_KEYS * 4, ctx->stream));
             HIP_TRY(ctx, rt_launch_classify(a, t, cursor, list, ctx->stream));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_list, ctx->stream));
             // the list length sizes the general kernel's grid: scan_kernel leaves it in cursor[0] ... which scatter does
@@ -464,10 +469,10 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                     const size_t pool_words = RT_HEAVY_TABLE_BYTES / 4;
                     rc = grow(ctx, &ctx->d_heavy, &ctx->heavy_bytes, 16 + 4 * (pool_words + cap * (RT_HEAVY_REC_WORDS + 1)));
                     if (rc) return rc;
-                    g2.heavy_count = (unsigned int*)ctx->d_heavy;
+                    g2.heavy_count = (unsigned int*)((char*)ctx->d_counters + RT_DEV_HEAVY_AT);   // zeroed with the counters
                     g2.fallback_count = g2.heavy_count + 1;
                     g2.heavy_pool_used = (unsigned long long*)(g2.heavy_count + 2);
-                    g2.heavy_pool = g2.heavy_count + 4;
+                    g2.heavy_pool = (unsigned int*)ctx->d_heavy;
                     g2.heavy_pool_words = (unsigned int)pool_words;
                     g2.heavy_rec = g2.heavy_pool + pool_words;
                     g2.fallback_list = g2.heavy_rec + cap * RT_HEAVY_REC_WORDS;
@@ -477,7 +482,6 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                     const double per_bounce = (double)ctx->n_hit * (1.0 + ctx->n_lights) / 8.0;
                     double min_work = RT_HEAVY_MIN_WORK / (per_bounce > 1.0 ? per_bounce : 1.0);
                     g2.heavy_min_work = force ? 0u : (unsigned int)(min_work < 1.0 ? 1.0 : min_work);
-                    HIP_TRY(ctx, hipMemsetAsync(g2.heavy_count, 0, 16, ctx->stream2));
                 }
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_list, 0));
                 if (coop) {
