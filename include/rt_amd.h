@@ -105,7 +105,8 @@ typedef struct {
 #define RT_FLAG_SEQUENCE              16 /* hint: the caller keeps several frames in flight on this GPU, one context
                                            each.  Same bytes; the library then favours how many
                                            workgroups are resident over the latency of one frame (the listed kernels
-                                           keep their generators in scratch rather than LDS)                         */
+                                           keep their generators in scratch rather than LDS; one launch instead of two
+                                           side by side)                                                             */
 
 /* Query tallies with the reference's meaning: primary = W*rows*samples*4; closest = TraceRay closest-hit queries
  * (src/renderer.h:40); shadow = hasIntersect / point-light occlusion queries (directionalLight.h:13); tests =

@@ -486,6 +486,12 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_list, 0));
                 if (coop) {
                     HIP_TRY(ctx, rt_launch_coop(g2, tg, ctx->stream2));
+                } else if (g2.heavy_cap > 0 && (p->flags & RT_FLAG_SEQUENCE)) {
+                    // frames in flight: one launch owns the whole list (one stream and one dispatch less per frame; the
+                    // split below buys latency for a frame on its own)
+                    g2.listed_mode = RT_MODE_ALL;
+                    HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream2));
+                    HIP_TRY(ctx, rt_launch_heavy(g2, tg, ctx->stream2));
                 } else if (g2.heavy_cap > 0) {
                     // the steady long pixels: first samples, hand-over, heavy kernel, resume kernel ...
                     g2.listed_mode = RT_MODE_STEADY;

@@ -455,8 +455,8 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
                 const bool eligible = guess > 0 && (agree >= RT_HEAVY_AGREE || a.heavy_min_work == 0)
                     && (unsigned long long)guess * (unsigned int)(a.samples - RT_HEAVY_PROBE) >= (unsigned long long)a.heavy_min_work;
                 if (a.listed_mode == RT_MODE_REST) { if (eligible) return; }
-                else if (!eligible) return;
-                else if (heavy_handover(a, rng, (unsigned int)o, guess, acc_color, acc_em, acc_st)) return;
+                else if (eligible) { if (heavy_handover(a, rng, (unsigned int)o, guess, acc_color, acc_em, acc_st)) return; }
+                else if (a.listed_mode == RT_MODE_STEADY) return;
             }
         }
     }

@@ -13,6 +13,7 @@
 #define RT_HEAVY_REC_WORDS 16
 #define RT_HEAVY_PROBE 4      /* samples the listed kernel does before a pixel can be handed over */
 // the listed render_kernel runs twice over the same list when long pixels are handed over (heavy_cap > 0)
+#define RT_MODE_ALL    0   /* owns every pixel of the list: hands the steady long ones over, keeps the rest */
 #define RT_MODE_STEADY 1   /* owns the pixels whose first samples draw equal counts and are long: hands them over */
 #define RT_MODE_REST   2   /* owns all other pixels */
 
