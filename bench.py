@@ -11,7 +11,7 @@ outside the timed region (they equal the reference's, tests/test_gpu_parity.py).
 
 Frames in flight.  A rank's share of a frame is bound by the latency of its longest pixels, not by throughput
 (3.3 ms for an eighth of the 4K frame whose arithmetic is worth 0.7 ms), so the K timed frames are
-rendered with up to --frames-in-flight (default 6, at every N) frames of a rank under way at once
+rendered with up to --frames-in-flight (default 8, at every N) frames of a rank under way at once
 (raytracer_amd/pipeline.py: host threads with a context each; gathers in frame order).  Every frame is rendered,
 gathered and reassembled in full inside the timed region.  After it, three frames run one at a time:
 `frame_latency_ms` is the time of such a frame, and the roofline object prices the render kernels of such a frame
@@ -44,7 +44,7 @@ def _frames_in_flight_arg(argv):
     return fif if fif else DEFAULT_IN_FLIGHT
 
 
-DEFAULT_IN_FLIGHT = 6
+DEFAULT_IN_FLIGHT = 8
 HW_QUEUES = "16"
 if _frames_in_flight_arg(sys.argv[1:]) > 1:
     os.environ["GPU_MAX_HW_QUEUES"] = HW_QUEUES
