@@ -220,7 +220,9 @@ int rt_create(rt_ctx** out, int device_ordinal)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_list, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gen, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking);
+    // (stream3 is created when the steady / rest split first runs: HIP deals streams to its hardware queues as they are
+    // created, and callers with many contexts in flight -- RT_FLAG_SEQUENCE, two streams each -- should not have idle
+    // third streams pushing busy ones onto shared queues)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_rest, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, RT_DEV_STATE_BYTES);
     if (e != hipSuccess) { rt_destroy(ctx); return RT_ERR_HIP; }
@@ -499,6 +501,7 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                     HIP_TRY(ctx, rt_launch_heavy(g2, tg, ctx->stream2));
                     // ... and beside them all other listed pixels
                     g2.listed_mode = RT_MODE_REST;
+                    if (!ctx->stream3) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
                     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_list, 0));
                     HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream3));
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_rest, ctx->stream3));
