@@ -30,7 +30,8 @@ typedef enum {
     RT_ERR_UNSUPPORTED  = -5,  /* material.reflection > 1 (unbounded recursion in the reference too),
                                   max_depth above RT_MAX_DEPTH, scene larger than the LDS staging budget     */
     RT_ERR_NO_SCENE     = -6,  /* rt_render_rows before rt_upload_scene                                      */
-    RT_ERR_DEVICE_FAULT = -7   /* the kernel reported an internal bound violation (bounce stack overflow)    */
+    RT_ERR_DEVICE_FAULT = -7,  /* the kernel reported an internal bound violation (bounce stack overflow)    */
+    RT_ERR_TOO_LARGE    = -8   /* rt_render_rows_static: rows * width above RT_STATIC_MAX_PIXELS              */
 } rt_status;
 
 enum { RT_SPHERE = 0, RT_PLANE = 1, RT_CUBE = 2 };        /* reference src/hittables/{sphere,plane,cube}.h   */
@@ -134,6 +135,22 @@ int rt_camera_init(rt_camera35f* cam, float fov_deg, float width, float height, 
  * rgb_out / emission_out may be host or device pointers (device pointers must belong to the context's GPU). */
 int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* params,
                    uint8_t* rgb_out, float* emission_out, rt_counters* counters);
+
+/* rt_render_rows for callers that cannot allocate.  It has no counterpart in the reference: it is for callers that
+ * may not call hipMalloc where they render -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation.  Same kernels, same bytes as rt_render_rows, but the call allocates nothing (no hipMalloc / hipFree, no
+ * stream or event creation): the per-frame device state and the pixel classes (a class per pixel and the list of
+ * bounce pixels, 6 bytes per pixel) live in a static device array of RT_STATIC_MAX_PIXELS * 6 + 4096 bytes that every
+ * GPU the library runs on holds until the process ends.
+ *   - rgb_dev / emission_dev must be DEVICE pointers on the context's GPU (host outputs would need a staging buffer);
+ *     emission_dev may be NULL; RT_FLAG_COUNT_* flags are rejected (RT_ERR_INVALID_ARG);
+ *   - params->rows * params->width above RT_STATIC_MAX_PIXELS is rejected with RT_ERR_TOO_LARGE: render the frame in
+ *     several calls over row ranges (rows are independent, rt_params.row0 / rows);
+ *   - every call on a GPU shares that GPU's array, whatever context it goes through: calls that overlap in time on one
+ *     GPU race.  One call at a time per GPU (calls through rt_render_rows do not touch the array and may overlap). */
+#define RT_STATIC_MAX_PIXELS (1 << 20)
+int rt_render_rows_static(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* params,
+                          uint8_t* rgb_dev, float* emission_dev);
 
 /* Depth probe of src/tests/singlePixel.cpp:65-90 (MaxRayDistance, src/renderer.h:204-219): one centre ray per
  * pixel; flags_out[x + y*width] = (maxDepth >= max_depth).  flags_out: host or device, width*height bytes. */

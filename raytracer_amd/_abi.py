@@ -9,7 +9,8 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
 RT_OK = 0
 RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_SCENE = -1, -2, -3, -4
-RT_ERR_UNSUPPORTED, RT_ERR_NO_SCENE, RT_ERR_DEVICE_FAULT = -5, -6, -7
+RT_ERR_UNSUPPORTED, RT_ERR_NO_SCENE, RT_ERR_DEVICE_FAULT, RT_ERR_TOO_LARGE = -5, -6, -7, -8
+RT_STATIC_MAX_PIXELS = 1 << 20
 RT_FLAG_COUNT_LIKE_REFERENCE = 1
 RT_FLAG_COUNT_EXECUTED = 2
 RT_FLAG_SINGLE_KERNEL = 4
@@ -17,7 +18,7 @@ RT_FLAG_FORCE_SAMPLE_PARALLEL = 8
 RT_FLAG_SEQUENCE = 16
 
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_render_tiles", "rt_probe_max_depth",
+    "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_render_rows_static", "rt_render_tiles", "rt_probe_max_depth",
     "rt_deinterleave_bands", "rt_last_kernel_ms", "rt_last_device_ms", "rt_last_hip_error", "rt_strerror",
     "rt_debug_rand", "rt_debug_quantise", "rt_debug_intersect",
 ]
@@ -78,6 +79,7 @@ def load():
     lib.rt_upload_scene.argtypes = [vp, ctypes.POINTER(SceneSoA)]
     lib.rt_camera_init.argtypes = [ctypes.POINTER(Camera35f)] + [ctypes.c_float] * 5
     lib.rt_render_rows.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), vp, vp, vp]
+    lib.rt_render_rows_static.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), vp, vp]
     lib.rt_probe_max_depth.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), vp]
     lib.rt_render_tiles.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), i32, i32, TILE_SINK, vp]
     lib.rt_deinterleave_bands.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32]

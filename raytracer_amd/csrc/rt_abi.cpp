@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -51,7 +52,9 @@ struct rt_ctx {
     const unsigned int* d_order = nullptr;       // hittable indices sorted by type (cooperative scans)
     const unsigned int* d_slot_of = nullptr;     // the inverse: place of every hittable in that order
     std::vector<float> h_centres_r2;             // host copy of (centre, r^2) per hittable
+    std::vector<float> h_prim;                   // staging for d_prim, sized by rt_upload_scene (no allocation per frame)
     float prim_cam[3] = { 0, 0, 0 }; bool prim_valid = false;
+    unsigned char* scratch = nullptr;            // this GPU's copy of the static scratch array (rt_render_rows_static)
 
     // small device words: 4 counters (u64) + fault flag
     unsigned long long* d_counters = nullptr;
@@ -76,6 +79,23 @@ struct rt_ctx {
 #define RT_DEV_HEAVY_AT  RT_DEV_WORDS_BYTES
 #define RT_DEV_HIST_AT   (RT_DEV_HEAVY_AT + 16)
 #define RT_DEV_STATE_BYTES (RT_DEV_HIST_AT + 2 * RT_MAX_KEYS * sizeof(unsigned int))
+
+// rt_render_rows_static (include/rt_amd.h): the per-frame device state and the pixel classes of a call that may not
+// allocate live in this array instead of in buffers the context allocates.  One copy per GPU the library runs on, held
+// until the process ends.  Layout: [0, RT_STATIC_STATE_BYTES) the RT_DEV_STATE_BYTES block | keys (u16 per pixel) |
+// pixel list (u32 per pixel), for at most RT_STATIC_MAX_PIXELS pixels.
+#define RT_STATIC_STATE_BYTES 4096
+#define RT_STATIC_KEYS_BYTES  ((size_t)RT_STATIC_MAX_PIXELS * 2)
+#define RT_STATIC_LIST_BYTES  ((size_t)RT_STATIC_MAX_PIXELS * 4)
+#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_STATE_BYTES + RT_STATIC_KEYS_BYTES + RT_STATIC_LIST_BYTES)
+static_assert(RT_DEV_STATE_BYTES <= RT_STATIC_STATE_BYTES, "the per-frame state block must fit its slot of the scratch array");
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
+// `scratch` above is a host-side stand-in, not a device address: every GPU holds its own copy at its own address, looked
+// up once per device (rt_create, with that device current) and kept here.  Host code only ever uses these pointers.
+#define RT_MAX_DEVICES 64
+static std::mutex g_scratch_mutex;
+static unsigned char* g_scratch_ptr[RT_MAX_DEVICES];
 
 #define HIP_TRY(ctx, expr)                                   \
     do {                                                     \
@@ -137,8 +157,11 @@ int check_params(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p)
     return RT_OK;
 }
 
-void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, KernelArgs& a)
+// `state`: the RT_DEV_STATE_BYTES block of the call (the context's own, or the one in the static scratch array)
+void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, KernelArgs& a, void* state = nullptr)
 {
+    unsigned long long* words = state ? (unsigned long long*)state : ctx->d_counters;
+    int* fault = (int*)(words + 5);
     std::memcpy(a.cam, cam, sizeof(float) * 35);
     a.width = p->width; a.height = p->height; a.samples = p->samples; a.max_depth = p->max_depth;
     a.seed_base = (unsigned int)(uint64_t)p->seed_base;
@@ -146,8 +169,8 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
     a.tiles_x = (p->width + 15) / 16; a.tiles_y = (p->rows + 15) / 16;
     a.n_hit = ctx->n_hit; a.n_lights = ctx->n_lights; a.n_mat = ctx->n_mat;
     a.hrec = ctx->d_hrec; a.lights = ctx->d_lights; a.mats = ctx->d_mats;
-    a.rgb = nullptr; a.emission = nullptr; a.counters = ctx->d_counters; a.fault = ctx->d_fault;
-    a.queue = (unsigned int*)(ctx->d_fault + 1);         // the word after it: reset with the counters
+    a.rgb = nullptr; a.emission = nullptr; a.counters = words; a.fault = fault;
+    a.queue = (unsigned int*)(fault + 1);                // the word after it: reset with the counters
     a.keys = nullptr; a.hist = nullptr; a.list = nullptr; a.list_count = 0; a.list_count_dev = nullptr;
     a.fallback_count = nullptr; a.fallback_list = nullptr; a.listed_mode = 0;
     a.heavy_count = nullptr; a.heavy_rec = nullptr; a.heavy_pool = nullptr; a.heavy_pool_used = nullptr;
@@ -163,7 +186,7 @@ int refresh_primary_terms(rt_ctx* ctx, const rt_camera35f* cam)
 {
     if (ctx->nonsphere || ctx->n_hit == 0) return RT_OK;
     if (ctx->prim_valid && std::memcmp(ctx->prim_cam, cam->position, 12) == 0) return RT_OK;
-    std::vector<float> prim((size_t)ctx->n_hit * 4);
+    std::vector<float>& prim = ctx->h_prim;              // sized at upload
     const rtm::vec3 eye(cam->position[0], cam->position[1], cam->position[2]);
     for (int i = 0; i < ctx->n_hit; ++i) {
         const float* r = &ctx->h_centres_r2[4 * (size_t)i];
@@ -172,7 +195,7 @@ int refresh_primary_terms(rt_ctx* ctx, const rt_camera35f* cam)
         prim[4 * (size_t)i + 3] = rtm::dot(oc, oc) - r[3];
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_prim, prim.data(), prim.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `prim` is a pageable temporary
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `prim` is pageable memory
     std::memcpy(ctx->prim_cam, cam->position, 12);
     ctx->prim_valid = true;
     return RT_OK;
@@ -193,6 +216,7 @@ const char* rt_strerror(int status)
     case RT_ERR_UNSUPPORTED:  return "unsupported (reflection > 1, max_depth > RT_MAX_DEPTH or scene too large)";
     case RT_ERR_NO_SCENE:     return "no scene uploaded";
     case RT_ERR_DEVICE_FAULT: return "device reported a bounce-stack overflow";
+    case RT_ERR_TOO_LARGE:    return "rt_render_rows_static: rows * width exceeds RT_STATIC_MAX_PIXELS (the static scratch array holds no more)";
     default:                  return "unknown status";
     }
 }
@@ -225,7 +249,17 @@ int rt_create(rt_ctx** out, int device_ordinal)
     // third streams pushing busy ones onto shared queues)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_rest, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, RT_DEV_STATE_BYTES);
-    if (e != hipSuccess) { rt_destroy(ctx); return RT_ERR_HIP; }
+    if (e == hipSuccess && device_ordinal < RT_MAX_DEVICES) {
+        // once per device, with that device current (DeviceGuard above): this GPU's address of the scratch array
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device_ordinal]) {
+            unsigned char* ptr = nullptr;
+            e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+            if (e == hipSuccess) g_scratch_ptr[device_ordinal] = ptr;
+        }
+        ctx->scratch = g_scratch_ptr[device_ordinal];
+    }
+    if (e != hipSuccess) { ctx->last_hip = (int)e; rt_destroy(ctx); return RT_ERR_HIP; }
     ctx->d_fault = (int*)(ctx->d_counters + 5);
     *out = ctx;
     return RT_OK;
@@ -371,6 +405,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     ctx->d_order = (const unsigned int*)((const float*)ctx->d_scene + prim_at + (size_t)nh * 4);
     ctx->d_slot_of = ctx->d_order + nh;
     ctx->h_centres_r2.resize((size_t)nh * 4);
+    ctx->h_prim.assign((size_t)nh * 4, 0.0f);
     for (int i = 0; i < nh; ++i) std::memcpy(&ctx->h_centres_r2[4 * (size_t)i], hrec + 8 * (size_t)i, 16);
     ctx->prim_valid = false;
     ctx->n_hit = nh; ctx->n_lights = nl; ctx->n_mat = nm;
@@ -379,8 +414,14 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     return RT_OK;
 }
 
-int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
-                   uint8_t* rgb_out, float* emission_out, rt_counters* counters)
+}  // extern "C"
+
+// rt_render_rows and rt_render_rows_static.  `no_alloc`: the call may not allocate -- its per-frame state and pixel
+// classes live in this GPU's copy of the static scratch array (ctx->scratch), outputs must be device pointers, no
+// tallies, and the sample-parallel route (which needs a stream pool) is left out: long pixels stay with the listed
+// kernel, same bytes.
+static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
+                            uint8_t* rgb_out, float* emission_out, rt_counters* counters, bool no_alloc)
 {
     int rc = check_params(ctx, cam, p);
     if (rc != RT_OK) return rc;
@@ -389,17 +430,25 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     if (!rgb_out && !emission_out && !count) return RT_ERR_INVALID_ARG;
     if (counters) std::memset(counters, 0, sizeof(*counters));
     if (p->rows == 0) { ctx->last_ms = 0.0f; ctx->last_total_ms = 0.0f; return RT_OK; }
+    const size_t npix = (size_t)p->width * p->rows;
+    if (no_alloc) {
+        if (count || counters) return RT_ERR_INVALID_ARG;
+        if (!ctx->scratch) return RT_ERR_NO_DEVICE;
+        if (npix > (size_t)RT_STATIC_MAX_PIXELS) return RT_ERR_TOO_LARGE;
+    }
 
     DeviceGuard g(ctx->device);
     if (!g.ok) return RT_ERR_NO_DEVICE;
 
-    rc = refresh_primary_terms(ctx, cam);
-    if (rc != RT_OK) return rc;
-    KernelArgs a;
-    fill_args(ctx, cam, p, a);
-    const size_t npix = (size_t)p->width * p->rows;
     const bool rgb_dev = rgb_out && is_device_pointer(rgb_out);
     const bool em_dev = emission_out && is_device_pointer(emission_out);
+    if (no_alloc && ((rgb_out && !rgb_dev) || (emission_out && !em_dev))) return RT_ERR_INVALID_ARG;   // host outputs need staging
+    rc = refresh_primary_terms(ctx, cam);
+    if (rc != RT_OK) return rc;
+    // the call's RT_DEV_STATE_BYTES block: tallies, fault flag, queue word, hand-over counters, histogram + cursor
+    unsigned char* const state = no_alloc ? ctx->scratch : (unsigned char*)ctx->d_counters;
+    KernelArgs a;
+    fill_args(ctx, cam, p, a, state);
     if (rgb_out) {
         if (rgb_dev) a.rgb = rgb_out;
         else { rc = grow(ctx, &ctx->d_stage_rgb, &ctx->stage_rgb_bytes, npix * 3); if (rc) return rc; a.rgb = (unsigned char*)ctx->d_stage_rgb; }
@@ -420,7 +469,8 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     // frames on the bounce stack <= reflection parents (max_depth) + refraction parents (66)
     t.deep = refraction_chain_bound() + p->max_depth > RT_STACK_SHALLOW || p->max_depth > RT_PEND_SHALLOW - 1;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_DEV_STATE_BYTES, ctx->stream));
+    // (the scratch array keeps the last call's contents: everything that must start at zero is in this block)
+    HIP_TRY(ctx, hipMemsetAsync(state, 0, RT_DEV_STATE_BYTES, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (count || (p->flags & RT_FLAG_SINGLE_KERNEL)) {
         // tallying builds and the A/B flag: the general kernel over every pixel
@@ -434,12 +484,18 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
         unsigned int n_listed = 0;
         bool rest = false;
         if (bounces) {
-            const size_t keys_bytes = (npix * 2 + 15) & ~(size_t)15;
-            rc = grow(ctx, &ctx->d_classes, &ctx->classes_bytes, keys_bytes + npix * 4 + 2 * RT_MAX_KEYS * 4);
-            if (rc) return rc;
-            a.keys = (unsigned short*)ctx->d_classes;
-            unsigned int* list = (unsigned int*)((char*)ctx->d_classes + keys_bytes);
-            a.hist = (unsigned int*)((char*)ctx->d_counters + RT_DEV_HIST_AT);        // zeroed with the counters
+            unsigned int* list;
+            if (no_alloc) {
+                a.keys = (unsigned short*)(ctx->scratch + RT_STATIC_STATE_BYTES);
+                list = (unsigned int*)(ctx->scratch + RT_STATIC_STATE_BYTES + RT_STATIC_KEYS_BYTES);
+            } else {
+                const size_t keys_bytes = (npix * 2 + 15) & ~(size_t)15;
+                rc = grow(ctx, &ctx->d_classes, &ctx->classes_bytes, keys_bytes + npix * 4);
+                if (rc) return rc;
+                a.keys = (unsigned short*)ctx->d_classes;
+                list = (unsigned int*)((char*)ctx->d_classes + keys_bytes);
+            }
+            a.hist = (unsigned int*)(state + RT_DEV_HIST_AT);                         // zeroed with the counters
             unsigned int* cursor = a.hist + RT_MAX_KEYS;
             HIP_TRY(ctx, rt_launch_classify(a, t, cursor, list, ctx->stream));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_list, ctx->stream));
@@ -465,13 +521,13 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                 // Large scenes: one wave per listed pixel, the lanes share every scan of the scene (coop_kernel)
                 const bool coop = ctx->n_hit >= RT_COOP_MIN_HIT && rt_launch_coop_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)
                                   && !force;
-                if (!coop && p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
+                if (!coop && !no_alloc && p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
                     // records + a pool for the pixels' written-out rand() sequences
                     size_t cap = n_listed < RT_HEAVY_CAP ? n_listed : RT_HEAVY_CAP;
                     const size_t pool_words = RT_HEAVY_TABLE_BYTES / 4;
                     rc = grow(ctx, &ctx->d_heavy, &ctx->heavy_bytes, 16 + 4 * (pool_words + cap * (RT_HEAVY_REC_WORDS + 1)));
                     if (rc) return rc;
-                    g2.heavy_count = (unsigned int*)((char*)ctx->d_counters + RT_DEV_HEAVY_AT);   // zeroed with the counters
+                    g2.heavy_count = (unsigned int*)(state + RT_DEV_HEAVY_AT);   // zeroed with the counters
                     g2.fallback_count = g2.heavy_count + 1;
                     g2.heavy_pool_used = (unsigned long long*)(g2.heavy_count + 2);
                     g2.heavy_pool = (unsigned int*)ctx->d_heavy;
@@ -522,7 +578,7 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     if (rgb_out && !rgb_dev) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, a.rgb, npix * 3, hipMemcpyDeviceToHost, ctx->stream));
     if (emission_out && !em_dev) HIP_TRY(ctx, hipMemcpyAsync(emission_out, a.emission, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
     unsigned long long words[6] = { 0, 0, 0, 0, 0, 0 };
-    HIP_TRY(ctx, hipMemcpyAsync(words, ctx->d_counters, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(words, state, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->evm, ctx->ev1));
     HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_total_ms, ctx->ev0, ctx->ev1));
@@ -534,6 +590,19 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
         counters->closest = words[0]; counters->shadow = words[1]; counters->tests = words[2]; counters->rand_draws = words[3]; counters->shaded = words[4];
     }
     return RT_OK;
+}
+
+extern "C" {
+
+int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
+                   uint8_t* rgb_out, float* emission_out, rt_counters* counters)
+{
+    return render_rows_impl(ctx, cam, p, rgb_out, emission_out, counters, false);
+}
+
+int rt_render_rows_static(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, uint8_t* rgb_dev, float* emission_dev)
+{
+    return render_rows_impl(ctx, cam, p, rgb_dev, emission_dev, nullptr, true);
 }
 
 int rt_render_tiles(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, int32_t tile, int32_t rows_per_chunk,

@@ -96,6 +96,12 @@ class Renderer:
             return {k: int(getattr(cnt, k)) for k in ("primary", "closest", "shadow", "tests", "rand_draws", "shaded")}
         return None
 
+    def render_rows_static(self, cam, params, rgb_dev, emission_dev=None):
+        """rt_render_rows_static: the variant that allocates nothing (device outputs only, at most RT_STATIC_MAX_PIXELS
+        pixels per call, one call at a time per GPU)."""
+        rc = self._lib.rt_render_rows_static(self._h, ctypes.byref(cam), ctypes.byref(params), _ptr(rgb_dev), _ptr(emission_dev))
+        self._check(rc, "rt_render_rows_static")
+
     def render(self, width, height, samples, max_depth, seed_base=0, emission=False, count=False, cam=None, **rows):
         """Convenience: whole frame (or the rows selected by row0/rows/band_rows/band_stride) into fresh host arrays.
         -> (rgb uint8 [rows, W, 3], emission float32 [rows, W, 4] or None, counters or None)"""
