@@ -109,6 +109,10 @@ typedef struct {
                                            keep their generators in scratch rather than LDS; one launch instead of two
                                            side by side)                                                             */
 
+#define RT_FLAG_RAYS_LISTED            32 /* bounce pixels of small scenes a lane per ray, 16 lanes per pixel, each ray
+                                           from a guessed place in the pixel's rand() sequence (rays_kernel): same
+                                           bytes, shorter latency for a small frame on its own, more work per ray   */
+
 /* Query tallies with the reference's meaning: primary = W*rows*samples*4; closest = TraceRay closest-hit queries
  * (src/renderer.h:40); shadow = hasIntersect / point-light occlusion queries (directionalLight.h:13); tests =
  * primitive intersect() calls; rand_draws = RANDOM_UNIT calls; shaded = closest-hit queries that hit (one

@@ -16,6 +16,7 @@ RT_FLAG_COUNT_EXECUTED = 2
 RT_FLAG_SINGLE_KERNEL = 4
 RT_FLAG_FORCE_SAMPLE_PARALLEL = 8
 RT_FLAG_SEQUENCE = 16
+RT_FLAG_RAYS_LISTED = 32
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_render_rows_static", "rt_render_tiles", "rt_probe_max_depth",

@@ -933,6 +933,241 @@ __global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
     }
 }
 
+// rays_kernel: listed pixels of small scenes, one lane per *ray*.
+//
+// A pixel's rays are serial only through the generator: one srand() per pixel (main.cpp:304) feeds all of its
+// 4 * samples rays in order, so ray q can only start where ray q-1 stopped drawing.  Everything else about a ray is a
+// function of its primary direction (q % 4: AntiAliasing is called with the same u, v for every sample, main.cpp:312)
+// and of the position in the pixel's rand() sequence at which it starts.  So a group of RAYS_GROUP lanes takes one
+// pixel, its lanes trace the pixel's next RAYS_GROUP rays side by side, each from a *guessed* position: the pixel's
+// sequence is written out ahead of use into an LDS ring (rt_device.hpp RngRing) and the guess for ray q is the start of
+// the first unsettled ray plus what the rays in between are expected to draw (per direction: what the last rays in that
+// direction drew).  Afterwards the group checks the guesses from the front: the first ray's start is always right; a
+// ray's start is right if all rays before it drew what was guessed for them.  Rays up to and including the first one
+// that drew something else stand ("settle"): their results are added to the pixel's sums in ray order (renderer.h:169-
+// 198, main.cpp:313-315), the next ray's true start is then known, and the rays behind trace again next round.  A round
+// costs the longest of its rays and settles at least one; where the draw counts repeat (a path whose shape does not
+// hang on the numbers drawn: glass, mirrors; or a rough surface that mostly sees the ground and the sky) it settles all
+// RAYS_GROUP.  No lane carries a pixel's whole serial chain any more, and a wave's four groups take their pixels from a
+// queue, so no wave waits for one long pixel.
+//
+// Every settled ray was traced from its true position in the sequence with the reference's operations, and the sums
+// are formed in the reference's order: same bytes as the serial loop.  Rays traced from a wrong guess only cost time
+// (whatever numbers they see, a path is bounded by its multiplier and depth, renderer.h:30,68).
+//
+// The ring holds RT_RING words.  Before each round half-waves extend it as far as it goes without overwriting words from
+// the first unsettled ray's start on (stream_turn_half: 31 words per turn), which leaves that ray >= 140 bounces
+// of numbers.  A first ray that needs more (a deep tree of a reflect-and-refract material) extends the sequence itself,
+// word by word, over the oldest words; the other rays of the round may then have read overwritten words and are all
+// traced again (`extended`).  A later ray that runs out of numbers is traced again too (`overflow`).
+constexpr int RAYS_GROUP = 16;
+constexpr int RAYS_WAVES = 4;
+constexpr int RAYS_GROUPS = RAYS_WAVES * 64 / RAYS_GROUP;      // pixels a workgroup has under way
+constexpr int RAYS_GROUP_WORDS = RT_RING + 16;                 // a group's LDS: the ring, 12 direction words, padding
+#ifndef RT_RAYS_MIN_WAVES
+#define RT_RAYS_MIN_WAVES 4
+#endif
+
+__device__ __forceinline__ unsigned int sel4(unsigned int v0, unsigned int v1, unsigned int v2, unsigned int v3, int i)
+{
+    return i == 0 ? v0 : i == 1 ? v1 : i == 2 ? v2 : v3;
+}
+__device__ __forceinline__ void set4(unsigned int& v0, unsigned int& v1, unsigned int& v2, unsigned int& v3, int i, unsigned int x)
+{
+    if (i == 0) v0 = x; else if (i == 1) v1 = x; else if (i == 2) v2 = x; else v3 = x;
+}
+
+template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
+__global__ __launch_bounds__(RAYS_WAVES * 64, RT_RAYS_MIN_WAVES) void rays_kernel(KernelArgs a)
+{
+    extern __shared__ float4 lds[];
+    SceneLds sc;
+    float* lds_free;
+    stage_scene(a, lds, sc, lds_free);
+    __builtin_amdgcn_s_setprio(3);
+
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int k = lane & (RAYS_GROUP - 1);                  // place in the group
+    const int gbase = lane & ~(RAYS_GROUP - 1);             // the group's first lane
+    unsigned int* const wave_lds = (unsigned int*)lds_free + (size_t)wave * 4 * RAYS_GROUP_WORDS;
+    unsigned int* const ring = wave_lds + (size_t)(lane >> 4) * RAYS_GROUP_WORDS;
+    float* const dirs = (float*)(ring + RT_RING);
+    const int n31 = lane & 31;                              // place in the half-wave that writes streams
+    const int nrays = 4 * a.samples;
+    const unsigned int count = (unsigned int)a.list_count;
+    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+    Counters cnt = { 0, 0, 0, 0, 0 };
+
+    // the group's state, the same in all of its lanes
+    bool have = false, done = false, probe = false;
+    unsigned int o = 0, seed = 0;
+    int first = 0;                                          // the pixel's first unsettled ray
+    unsigned int lo_w = 31u, hi = 31u;                      // stream word at which ray `first` starts; words below hi exist
+    unsigned int g0 = 3u, g1 = 3u, g2 = 3u, g3 = 3u;        // words a ray in direction d is expected to draw
+    unsigned int l0 = 3u, l1 = 3u, l2 = 3u, l3 = 3u;        // words the last settled ray in direction d drew
+    v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0), res_color = mk(0, 0, 0), res_em = mk(0, 0, 0);
+    float acc_st = 0.0f, res_st = 0.0f;
+
+    // Every round settles at least one ray of every pixel under way and the queue is finite: the bound is never reached.
+    const unsigned long long bound = (unsigned long long)count * (unsigned long long)(nrays + 1) + 4ull;
+    for (unsigned long long round = 0; round < bound; ++round) {
+        // ---- groups without a pixel take the next one from the queue
+        bool fresh = false;
+        if (!have && !done) {
+            unsigned int i = 0;
+            if (k == 0) i = atomicAdd(a.queue, 1u);
+            i = (unsigned int)__shfl((int)i, gbase);
+            if (i < count) {
+                o = a.list[i];
+                const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
+                const int y = frame_row(a, r);
+                seed = a.seed_base + (unsigned int)(x + y * a.width);                    // rand.h:7, main.cpp:304
+                first = 0; lo_w = 31u; hi = 31u;
+                g0 = g1 = g2 = g3 = 3u; l0 = l1 = l2 = l3 = 3u;
+                acc_color = mk(0, 0, 0); acc_em = mk(0, 0, 0); res_color = mk(0, 0, 0); res_em = mk(0, 0, 0);
+                acc_st = 0.0f; res_st = 0.0f;
+                have = true; fresh = true; probe = true;
+                if (k < 4) {                                                             // renderer.h:140,167-191 over main.cpp:301-307
+                    Camera cam;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) cam.pos[j] = a.cam[j];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { cam.ip[j] = a.cam[3 + j]; cam.iv[j] = a.cam[19 + j]; }
+                    const float u = ((float)x / (float)a.width) * 2.0f - 1.0f;
+                    const float v = -(((float)y / (float)a.height) * 2.0f - 1.0f);
+                    const float offX = 0.5f / a.width, offY = 0.5f / a.height;
+                    const v3 dd = uv_to_direction(cam, (k & 1) ? u + offX : u - offX, (k & 2) ? v + offY : v - offY);
+                    dirs[3 * k + 0] = dd.x; dirs[3 * k + 1] = dd.y; dirs[3 * k + 2] = dd.z;
+                }
+            } else {
+                done = true;
+            }
+        }
+        if (__ballot(have) == 0ull) break;
+
+        // ---- streams.  Half-wave h writes for groups 2h and 2h + 1, one after the other; lane n of the half holds word
+        // base + n of a run of 31.
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int sl = (lane & 32) + pass * RAYS_GROUP;                               // a lane of the served group
+            unsigned int* const sring = wave_lds + (size_t)(sl >> 4) * RAYS_GROUP_WORDS;
+            const bool s_have = __shfl((int)have, sl) != 0, s_fresh = __shfl((int)fresh, sl) != 0;
+            const unsigned int s_seed = (unsigned int)__shfl((int)seed, sl);
+            const unsigned int s_lo = (unsigned int)__shfl((int)lo_w, sl), s_hi = (unsigned int)__shfl((int)hi, sl);
+            if (__ballot(s_fresh) != 0ull) {
+                // srand(seed): words r[3..30], r[0..2] are the stream's first 31 words, oldest first; then the 310
+                // discarded outputs, ten turns (glibc srandom_r)
+                unsigned int wv = 0u;
+                if (n31 < 31) wv = srand_word(s_seed, n31 + 3 >= 31 ? n31 + 3 - 31 : n31 + 3);
+#pragma unroll 1
+                for (int t = 0; t < 10; ++t) wv = stream_turn_half(wv);
+                if (s_fresh && n31 < 31) sring[n31] = wv;                                 // words 0..30; draw 0 is word 31
+            }
+            __builtin_amdgcn_wave_barrier();
+            // as many turns as fit without overwriting words from s_lo - 31 on
+            const int turns = s_have ? (int)((s_lo - 31u + (unsigned int)RT_RING - s_hi) / 31u) : 0;
+            const int other = __shfl(turns, lane ^ 32);
+            const int tmax = __builtin_amdgcn_readfirstlane(turns > other ? turns : other);
+            unsigned int wv = 0u;
+            if (n31 < 31 && turns > 0) wv = sring[(s_hi - 31u + (unsigned int)n31) & (RT_RING - 1)];
+#pragma unroll 1
+            for (int t = 0; t < tmax; ++t) {
+                const unsigned int nv = stream_turn_half(wv);
+                if (t < turns) {
+                    wv = nv;
+                    if (n31 < 31) sring[(s_hi + 31u * (unsigned int)t + (unsigned int)n31) & (RT_RING - 1)] = wv;
+                }
+            }
+        }
+        if (have) hi += 31u * ((lo_w - 31u + (unsigned int)RT_RING - hi) / 31u);
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- trace: lane k takes ray first + k from its guessed position
+        const int q = first + k, d = q & 3, d0 = first & 3;
+        const bool active = have && q < nrays;
+        unsigned int pre = (unsigned int)(k >> 2) * (g0 + g1 + g2 + g3);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < (k & 3)) pre += sel4(g0, g1, g2, g3, (d0 + j) & 3);
+        const unsigned int my_guess = sel4(g0, g1, g2, g3, d);
+        const unsigned int start = lo_w + pre;
+        RngRing rng;
+        rng.start(ring, start, hi, lo_w + (unsigned int)RT_RING, k == 0);
+        PathOut p;
+        p.color = mk(0, 0, 0); p.emission = mk(0, 0, 0); p.strength = 0.0f; p.maxDepth = 1;
+        if (active) {
+            const v3 dir = mk(dirs[3 * d + 0], dirs[3 * d + 1], dirs[3 * d + 2]);
+            p = trace_path<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, RngRing, RT_LISTED_BATCH>(sc, rng, origin, dir, a.max_depth, cnt, a.fault);
+        }
+        v3 pc = p.color;                                                                 // renderer.h:169
+        if (p.maxDepth != 1) { const float md = (float)p.maxDepth; pc = mk(pc.x / md, pc.y / md, pc.z / md); }
+        const unsigned int drew = rng.ndraws;
+
+        // ---- which rays stand
+        const bool usable = active && !rng.overflow;
+        const unsigned int m_usable = (unsigned int)(__ballot(usable) >> gbase) & 0xFFFFu;
+        const unsigned int m_exact = (unsigned int)(__ballot(usable && drew == my_guess) >> gbase) & 0xFFFFu;
+        const int jm = __builtin_ctz(~m_exact | 0x10000u);                               // first ray that drew something else
+        int settled = jm + (int)((m_usable >> jm) & 1u);                                 // (bit 16 is clear)
+        if (__shfl((int)rng.extended, gbase) != 0) settled = 1;
+        if (!have) settled = 0;
+        const unsigned int new_hi = (unsigned int)__shfl((int)rng.hi, gbase);            // the first ray may have extended it
+        const unsigned int new_lo = (unsigned int)__shfl((int)(start + drew), gbase + (settled > 0 ? settled - 1 : 0));
+
+        // ---- their results, in ray order (renderer.h:167-198, main.cpp:313-315)
+        int smax = __builtin_amdgcn_readlane(settled, 0);
+        { const int s1 = __builtin_amdgcn_readlane(settled, 16), s2 = __builtin_amdgcn_readlane(settled, 32), s3 = __builtin_amdgcn_readlane(settled, 48);
+          smax = smax > s1 ? smax : s1; smax = smax > s2 ? smax : s2; smax = smax > s3 ? smax : s3; }
+#pragma unroll 1
+        for (int j = 0; j < smax; ++j) {
+            const int src = gbase + j;
+            const float cx = __shfl(pc.x, src), cy = __shfl(pc.y, src), cz = __shfl(pc.z, src);
+            const unsigned int cj = (unsigned int)__shfl((int)drew, src);
+            float ex = 0.0f, ey = 0.0f, ez = 0.0f, es = 0.0f;
+            if (EMISSION) { ex = __shfl(p.emission.x, src); ey = __shfl(p.emission.y, src); ez = __shfl(p.emission.z, src); es = __shfl(p.strength, src); }
+            if (j < settled) {
+                const int dj = (first + j) & 3;
+                res_color = res_color + mk(cx, cy, cz);
+                if (EMISSION) {
+                    res_em = res_em + mk(ex, ey, ez);
+                    res_st = (dj == 0) ? es : gmax(res_st, es);                          // renderer.h:171,179,187,195
+                }
+                if (dj == 3) {                                                           // renderer.h:197-198, main.cpp:313-315
+                    res_color = res_color * 0.25f;
+                    acc_color = acc_color + mk(clamp01(res_color.x), clamp01(res_color.y), clamp01(res_color.z));
+                    res_color = mk(0, 0, 0);
+                    if (EMISSION) {
+                        res_em = res_em * 0.25f;
+                        acc_em = acc_em + mk(clamp01(res_em.x), clamp01(res_em.y), clamp01(res_em.z));
+                        acc_st += res_st;
+                        res_em = mk(0, 0, 0); res_st = 0.0f;
+                    }
+                }
+                // what to expect of the next rays in this direction: a count seen twice in a row
+                if (cj == sel4(l0, l1, l2, l3, dj)) set4(g0, g1, g2, g3, dj, cj);
+                set4(l0, l1, l2, l3, dj, cj);
+            }
+        }
+        if (probe) {
+            // a pixel's first round: what the first ray in each direction drew is the first guess for that direction, even
+            // if that ray started at a wrong place (a path that does not hang on the numbers draws the same count anyway)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned int cj = (unsigned int)__shfl((int)drew, gbase + j);
+                if (have && ((m_usable >> j) & 1u)) { set4(g0, g1, g2, g3, j, cj); set4(l0, l1, l2, l3, j, cj); }
+            }
+            probe = false;
+        }
+        if (have) {
+            first += settled; lo_w = new_lo; hi = new_hi;
+            if (first >= nrays) {
+                if (k == 0) store_pixel<EMISSION>(a, (size_t)o, acc_color, acc_em, acc_st);
+                have = false;
+            }
+        }
+    }
+}
+
 // resume_kernel: the serial pixel loop for what heavy_kernel gave up on, one lane per pixel, from the sample its record
 // names and the generator state found in the pixel's stream.
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
@@ -1120,6 +1355,15 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 // ---- launchers ------------------------------------------------------------------------------------------------
 using namespace rt;
 
+// kernel variants by (emission buffer, reflect-and-refract material, planes or cubes).  RT_DEV_FAST (experiments only):
+// just the two that the bench workloads use, for a quick build.
+#ifdef RT_DEV_FAST
+#define RT_ALL_VARIANTS(X) X(false, false, false) X(false, true, true)
+#else
+#define RT_ALL_VARIANTS(X) X(false, false, false) X(false, false, true) X(false, true, false) X(false, true, true) \
+                           X(true, false, false)  X(true, false, true)  X(true, true, false)  X(true, true, true)
+#endif
+
 template <class K>
 static hipError_t launch_with_lds(K k, const KernelArgs& a, int blocks, size_t lds_bytes, hipStream_t stream)
 {
@@ -1166,10 +1410,7 @@ hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStrea
         return !t.listed ? launch_general<false, false, E, M, N>(a, t.deep, blocks, lds, stream) \
              : lds_rng   ? launch_general<true, true, E, M, N>(a, t.deep, blocks, lds, stream)   \
                          : launch_general<true, false, E, M, N>(a, t.deep, blocks, lds, stream);
-    RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
-    RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)
-    RT_DISPATCH(true, false, false)  RT_DISPATCH(true, false, true)
-    RT_DISPATCH(true, true, false)   RT_DISPATCH(true, true, true)
+    RT_ALL_VARIANTS(RT_DISPATCH)
 #undef RT_DISPATCH
     return hipErrorInvalidValue;
 }
@@ -1224,10 +1465,51 @@ hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream
         if (e != hipSuccess) return e;                                                                                    \
         return t.deep ? launch_with_lds(resume_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, rblocks, lds, stream)             \
                       : launch_with_lds(resume_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, rblocks, lds, stream); }
-    RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
-    RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)
-    RT_DISPATCH(true, false, false)  RT_DISPATCH(true, false, true)
-    RT_DISPATCH(true, true, false)   RT_DISPATCH(true, true, true)
+    RT_ALL_VARIANTS(RT_DISPATCH)
+#undef RT_DISPATCH
+    return hipErrorInvalidValue;
+}
+
+static size_t rays_lds_bytes(int n_hit, int n_lights, int n_mat)
+{
+    size_t nm = (size_t)((10 * n_mat + 3) & ~3);
+    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)RAYS_GROUPS * RAYS_GROUP_WORDS * 4 + 16;
+}
+
+bool rt_launch_rays_fits(int n_hit, int n_lights, int n_mat)
+{
+    return rays_lds_bytes(n_hit, n_lights, n_mat) <= 160 * 1024;
+}
+
+template <class K>
+static hipError_t launch_rays(K k, const KernelArgs& a, size_t lds_bytes, hipStream_t stream)
+{
+    int blocks = (a.list_count + RAYS_GROUPS - 1) / RAYS_GROUPS;
+    if (blocks <= 0) return hipSuccess;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    // as many workgroups as are resident at once: their groups take pixels from the queue until it is empty
+    int per_cu = 0, dev = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, RAYS_WAVES * 64, lds_bytes);
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    const int resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    if (blocks > resident) blocks = resident;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(RAYS_WAVES * 64), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+// rays_kernel over the pixel list: a lane per ray, 16 lanes per pixel.
+hipError_t rt_launch_rays(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
+{
+    const size_t lds = rays_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+#define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N)                          \
+        return t.deep ? launch_rays(rays_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, lds, stream)         \
+                      : launch_rays(rays_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, lds, stream);
+    RT_ALL_VARIANTS(RT_DISPATCH)
 #undef RT_DISPATCH
     return hipErrorInvalidValue;
 }
@@ -1273,10 +1555,7 @@ hipError_t rt_launch_coop(const KernelArgs& a, const LaunchTraits& t, hipStream_
 #define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N)                                \
         return t.deep ? launch_coop(coop_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream)       \
                       : launch_coop(coop_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, stream);
-    RT_DISPATCH(false, false, false) RT_DISPATCH(false, false, true)
-    RT_DISPATCH(false, true, false)  RT_DISPATCH(false, true, true)
-    RT_DISPATCH(true, false, false)  RT_DISPATCH(true, false, true)
-    RT_DISPATCH(true, true, false)   RT_DISPATCH(true, true, true)
+    RT_ALL_VARIANTS(RT_DISPATCH)
 #undef RT_DISPATCH
     return hipErrorInvalidValue;
 }

@@ -75,6 +75,8 @@ hipError_t rt_launch_classify(const KernelArgs& a, const LaunchTraits& t, unsign
 hipError_t rt_launch_direct(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 bool rt_launch_heavy_fits(int n_hit, int n_lights, int n_mat);
 bool rt_launch_coop_fits(int n_hit, int n_lights, int n_mat);
+bool rt_launch_rays_fits(int n_hit, int n_lights, int n_mat);
+hipError_t rt_launch_rays(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_coop(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_probe(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);

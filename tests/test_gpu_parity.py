@@ -298,6 +298,35 @@ def test_sample_parallel_route_equals_serial(rt):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("name,W,H,samples,depth", [
+    ("default4", 333, 77, 8, 10),
+    ("default4", 160, 90, 1, 10),            # four rays per pixel: one lane in four of a group has a ray
+    ("default4", 96, 54, 67, 10),            # more rays than a 64-sample pixel
+    ("glass_mirror", 200, 120, 16, 12),      # mixed material: draw counts change from ray to ray
+    ("glass_mirror", 64, 64, 5, 20),         # deep stack variant
+    ("random10", 256, 128, 9, 12),
+    ("cube", 96, 64, 6, 5),
+    ("degenerate", 120, 72, 4, 64),
+])
+def test_ray_parallel_route_gives_the_same_bytes(rt, name, W, H, samples, depth):
+    """RT_FLAG_RAYS_LISTED renders the bounce pixels of a small scene a lane per ray, each ray from a guessed place in the
+    pixel's rand() sequence, and keeps what the guesses got right (rays_kernel).  Same bytes as the oracle, with and
+    without the emission buffer, also combined with the sequence hint."""
+    from raytracer_amd import _abi
+    sc = scenes.BUILTIN[name]()
+    want_rgb, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, 31, threads=8)
+    rt.upload_scene(sc)
+    cam = ra.camera35f(sc, W, H)
+    for flags in (_abi.RT_FLAG_RAYS_LISTED, _abi.RT_FLAG_RAYS_LISTED | _abi.RT_FLAG_SEQUENCE, 0):
+        rgb = np.zeros((H, W, 3), np.uint8); em = np.zeros((H, W, 4), np.float32)
+        rt.render_rows(cam, rt.params(W, H, samples, depth, 31, flags=flags), rgb, em)
+        assert np.array_equal(rgb, want_rgb), flags
+        assert np.array_equal(em.view(np.uint32), want_em.view(np.uint32)), flags
+        rgb = np.zeros((H, W, 3), np.uint8)
+        rt.render_rows(cam, rt.params(W, H, samples, depth, 31, flags=flags), rgb, None)
+        assert np.array_equal(rgb, want_rgb), (flags, "rgb only")
+
+
 def test_rows_and_cyclic_bands_are_partition_independent(rt):
     sc = scenes.glass_mirror()
     W, H, samples, depth, seed = 120, 100, 2, 6, 9

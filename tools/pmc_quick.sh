@@ -14,5 +14,5 @@ for r in csv.DictReader(open("$OUT/a/a_counter_collection.csv")):
     if r["Counter_Name"]=="GRBM_GUI_ACTIVE": agg[k]["_ms"]+=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
 for k,v in sorted(agg.items(), key=lambda kv:-kv[1]["_ms"])[:8]:
     c=len(n[k]); cyc=v["GRBM_GUI_ACTIVE"]/c/8
-    print("%s calls %d ms %.2f waves %.0f waves/SIMD %.2f VALUutil %.1f%% laneutil %.1f%% wait %.0f%%" % (k, c, v["_ms"]/c, v["SQ_WAVES"]/c, 4*v["SQ_WAVE_CYCLES"]/c/cyc/1024, 100*v["SQ_INSTS_VALU"]/c/(1024*cyc/2), 100*v["SQ_THREAD_CYCLES_VALU"]/(64*v["SQ_ACTIVE_INST_VALU"]), 100*v["SQ_WAIT_ANY"]/v["SQ_WAVE_CYCLES"]))
+    print("%s calls %d ms %.2f waves %.0f waves/SIMD %.2f VALUutil %.1f%% laneutil %.1f%% wait %.0f%%" % (k, c, v["_ms"]/c, v["SQ_WAVES"]/c, 4*v["SQ_WAVE_CYCLES"]/c/cyc/1024, 100*v["SQ_INSTS_VALU"]/c/(1024*cyc/2), 100*v["SQ_THREAD_CYCLES_VALU"]/max(1.0,64*v["SQ_ACTIVE_INST_VALU"]), 100*v["SQ_WAIT_ANY"]/max(1.0,v["SQ_WAVE_CYCLES"])), "valu_winstr %.3e" % (v["SQ_INSTS_VALU"]/c))
 PY
