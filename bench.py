@@ -82,13 +82,37 @@ def algorithmic_flops(cnt, scene, n_pixels, samples):
             76.0 * bounces + 19.0 * n_pixels * samples + 9.0 * n_pixels)
 
 
+def host_threads():
+    """Worker threads for the CPU legs: hardware_concurrency() - 1 like src/main.cpp:268, where the hardware is what this
+    process may use -- its CPU affinity set, and on a GPU box the share a one-GPU job is given (os.cpu_count() reports the
+    whole machine there; the box exports its share as OMP_NUM_THREADS and kills jobs that start more workers)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(1, n - 1)
+
+
+def load_pmc(workload):
+    """profiles/pmc_<workload>.json (tools/pmc_frame.py over the rocprofv3 --pmc passes of this bench command): executed VALU
+    wave instructions, executed FP32 operations and HBM bytes of one frame.  None when the workload has no profile."""
+    path = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        return json.load(fh), os.path.relpath(path, ROOT)
+
+
 def cpu_baseline(scene, W, H, samples, depth, count_rays, budget_s=20.0):
     """Times the reference's own multi-threaded renderer (oracle/_ref/ref_oracle: the unmodified reference headers
     driven through the reference's ThreadPool with 16x16 tiles, src/main.cpp:268-331) on this box's host cores, on a
     bounded sample of the same workload: every row_step-th row of the frame at the full spp.  count_rays(row_step)
     returns the exact closest-hit query count of those rows.  Falls back to the plain-C port (kind "port") when the
     reference binary is absent; when both exist the port's rate is reported alongside."""
-    cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))) - 1)   # hardware_concurrency()-1, main.cpp:268
+    cores = host_threads()
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_oracle")
     port = os.path.join(ROOT, "oracle", "rt_oracle")
     if not os.path.exists(port):
@@ -114,7 +138,7 @@ def cpu_baseline(scene, W, H, samples, depth, count_rays, budget_s=20.0):
             out[kind] = best
     kind = "reference" if "reference" in out else "port"
     b = out[kind]
-    res = {"value": round(b["value"], 3), "unit": "Mrays/s", "cores": cores, "kind": kind,
+    res = {"value": round(b["value"], 3), "unit": "Mrays/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": kind,
            "sample": "every %d-th row (%d rows) of the %dx%d frame at %d spp, %.0f ms, 16x16 tiles on %d worker threads" % (
                b["step"], b["rows"], W, H, samples, b["ms"], cores)}
     if kind == "reference" and "port" in out:
@@ -131,6 +155,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0, help="frames of one rank under way at once (default %d)" % DEFAULT_IN_FLIGHT)
     ap.add_argument("--workload", default="default4_4k_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed frame with the CPU oracle")
     ap.add_argument("--flags", type=int, default=0, help="extra rt_params.flags for A/B runs (4 = RT_FLAG_SINGLE_KERNEL, 8 = RT_FLAG_FORCE_SAMPLE_PARALLEL)")
     args = ap.parse_args()
 
@@ -204,6 +229,20 @@ def main():
     frame = pipe.run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
+    # untimed: the last frame of the timed region against the CPU oracle (the plain-C port, pinned to the reference by
+    # tests/test_oracle_golden.py) on every vstep-th row -- the rows the cpu_baseline leg samples
+    verified = None
+    if rank == 0 and not args.no_verify:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        vstep = 16 if len(scene.hittables) < 256 else H // 3       # (large scenes: minutes per row on the CPU)
+        vrows = (H + vstep - 1) // vstep
+        tv0 = time.perf_counter()
+        want = oracle_lib.render_strided(scene, W, H, samples, depth, seed, row0=0, rows=vrows, row_step=vstep, threads=host_threads())[0]
+        got = frame[::vstep].cpu().numpy()
+        bad = int((got != want).any(axis=-1).sum())
+        verified = {"rows": vrows, "row_step": vstep, "pixels": int(vrows * W), "differing_pixels": bad, "identical": bad == 0,
+                    "against": "oracle/librt_oracle.so (CPU port), %.1f s" % (time.perf_counter() - tv0)}
     # untimed: three frames one at a time -- the latency of a frame on its own and the durations of its kernels when
     # they do not overlap with another frame's (what the roofline object prices)
     latency_ms = []
@@ -224,7 +263,7 @@ def main():
 
     # exact tallies of this frame (untimed): the counting build issues every query the reference issues
     pc = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank)
-    tally_note = "queries of the reference algorithm for this frame (device tally == oracle tally)"
+    tally_note = "queries of the reference algorithm for this frame, tallied by the device's counting build (equal to the oracle's tallies: tests/test_gpu_parity.py, tests/test_gpu_fullsize.py)"
     if len(scene.hittables) >= 256:
         # the counting build is one lane per pixel: minutes for a large scene.  Tally every 32nd row of this rank's
         # rows and scale -- an estimate, flagged as such.
@@ -255,10 +294,34 @@ def main():
         sec_per_step = elapsed / args.steps
         value = rays / sec_per_step / 1e6
         whole_region = flops / sec_per_step / 1e12 / world     # lower bound: everything of a frame, host gaps included
-        achieved = flops / (kms * 1e-3) / 1e12 / world       # per GPU: slowest rank's kernel time
-        basis = ("duration of the frame's render kernels (direct, listed, heavy: they overlap) from HIP events" +
+        algorithmic = flops / (kms * 1e-3) / 1e12 / world      # per GPU: slowest rank's kernel time
+        basis = ("the span of the frame's render kernels (direct, listed, heavy: they overlap) from HIP events on the context's stream" +
                  ("" if in_flight == 1 else ", measured on three frames run one at a time after the timed region (inside it "
                   "the kernels of the %d frames in flight overlap)" % in_flight))
+        # What the kernels execute, from the committed PMC passes of this command (counts per frame do not depend on the
+        # clock) over the kernel time measured here.  Peak issue rate: one wave64 VALU instruction per SIMD per 2 cycles,
+        # 1024 SIMDs x 2.4 GHz / 2 -- the rate the 157.3 TFLOP/s figure assumes with every slot an FMA.
+        peak_issue = 256 * 4 * 2.4e9 / 2.0 / 1e9                 # G wave instructions / s
+        pmc, pmc_path = load_pmc(args.workload)
+        roof = {"bound": "valu", "achieved": None, "peak": round(peak_issue, 1), "unit": "G wave64 VALU instructions/s", "frac": None,
+                "traffic": None, "kernel_ms": round(kms, 3)}
+        if pmc and world == 1:
+            pf = pmc["per_frame"]
+            issue = pf["valu_wave_instructions"] / (kms * 1e-3) / 1e9
+            ex = pf["executed_flops"] / (kms * 1e-3) / 1e12
+            roof.update({"achieved": round(issue, 1), "frac": round(issue / peak_issue, 4), "valu_issue_frac": round(issue / peak_issue, 4),
+                         "executed_flops": pf["executed_flops"], "executed_tflops": round(ex, 2), "executed_frac": round(ex / PEAK_FP32_TFLOPS, 4),
+                         "fma_share": round(pf["fma_share_of_fp32_instructions"], 4), "lane_utilisation": round(pf["lane_utilisation"], 4),
+                         "traffic": int(pf["hbm_bytes"]), "traffic_note": "HBM bytes of one frame, 2 x FETCH_SIZE + WRITE_SIZE over its kernels; "
+                         "algorithmic bytes: %d (3 B per pixel)" % (3 * W * H), "pmc": pmc_path})
+        roof.update({"algorithmic_flops": flops, "algorithmic_tflops": round(algorithmic, 3), "algorithmic_frac": round(algorithmic / PEAK_FP32_TFLOPS, 4),
+                     "peak_fp32_tflops": PEAK_FP32_TFLOPS, "timed_region_algorithmic_frac": round(whole_region / PEAK_FP32_TFLOPS, 4),
+                     "note": "frac = VALU issue fraction of a frame: executed wave64 VALU instructions (rocprofv3 --pmc SQ_INSTS_VALU, "
+                             "profiles/) / kernel_ms / peak issue rate; kernel_ms = " + basis + ". executed_* = FP32 operations the "
+                             "kernels execute (add + mul + trans + 2 x fma wave instructions x 64 x lane utilisation): nothing is "
+                             "contracted (bit parity), so 0.5 of the FMA peak is the ceiling. algorithmic_* = SURVEY 8d flop table x the "
+                             "reference algorithm's query tallies: work the kernels partly avoid (candidate lists, shadow pruning), "
+                             "not hardware utilisation."})
         line = {
             "metric": "Mrays/s (primary+secondary) at 4K/64spp; % FP32 VALU peak",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -271,15 +334,9 @@ def main():
             "rays": {"primary": tot["primary"], "secondary": tot["closest"] - tot["primary"], "shadow": tot["shadow"],
                      "primitive_tests": tot["tests"], "rng_draws": tot["rand_draws"],
                      "note": tally_note},
+            "verified": verified,
             "kernel_ms": round(kms, 3), "device_ms_rank0": round(float(np.mean(device_ms)), 3),
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                         "timed_region_frac": round(whole_region / PEAK_FP32_TFLOPS, 4),
-                         "note": "algorithmic FP32 flops of the frame (SURVEY 8d table x the reference algorithm's query "
-                                 "tallies) / " + basis + ". The kernels execute fewer flops than that: per-wave candidate lists "
-                                 "and shadow-query pruning skip tests known to fail, so frac can pass the 0.5 that "
-                                 "un-fused FP32 code could reach by brute force. Executed VALU issue utilisation per "
-                                 "kernel (PMC counters) is in profiles/"},
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             def count_rays(step):
@@ -288,6 +345,10 @@ def main():
                 return rt.render_rows(cam, ps, block[:n], count=True)["closest"]
             line["cpu_baseline"] = cpu_baseline(scene, W, H, samples, depth, count_rays)
         print(json.dumps(line), flush=True)
+        if verified is not None and not verified["identical"]:
+            for r in rts:
+                r.close()
+            raise SystemExit("bench.py: the timed frame differs from the CPU oracle in %d pixels" % verified["differing_pixels"])
     for r in rts:
         r.close()
     if world > 1:

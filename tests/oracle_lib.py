@@ -40,6 +40,10 @@ def lib():
         _lib.ro_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.ro_render_strided.restype = ctypes.c_int
+        _lib.ro_render_strided.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         _lib.ro_camera_init.argtypes = [ctypes.c_void_p] + [ctypes.c_float] * 5
         _lib.ro_probe_max_depth.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_void_p]
         _lib.ro_srand.argtypes = [ctypes.c_void_p, ctypes.c_uint]
@@ -78,6 +82,21 @@ def render(scene, W, H, samples, maxdepth, seed_base=0, row0=0, rows=None, threa
                          rgb.ctypes.data, em.ctypes.data if em is not None else None, ctypes.byref(cnt))
     if rc != 0:
         raise ValueError("ro_render rejected the arguments")
+    del keep
+    return rgb, em, {"primary": cnt.primary, "closest": cnt.closest, "shadow": cnt.shadow, "tests": cnt.tests, "rand_draws": cnt.draws}
+
+
+def render_strided(scene, W, H, samples, maxdepth, seed_base=0, row0=0, rows=1, row_step=1, threads=1, want_emission=False):
+    """Rows y = row0 + i * row_step, i < rows, packed.  -> (rgb uint8 [rows,W,3], emission or None, counters dict)"""
+    rs, keep = _pack(scene)
+    cam = camera(scene, W, H)
+    rgb = np.zeros((rows, W, 3), dtype=np.uint8)
+    em = np.zeros((rows, W, 4), dtype=np.float32) if want_emission else None
+    cnt = RoCounters()
+    rc = lib().ro_render_strided(ctypes.byref(rs), cam.ctypes.data, W, H, samples, maxdepth, seed_base, row0, rows, row_step, threads,
+                                 rgb.ctypes.data, em.ctypes.data if em is not None else None, ctypes.byref(cnt))
+    if rc != 0:
+        raise ValueError("ro_render_strided rejected the arguments")
     del keep
     return rgb, em, {"primary": cnt.primary, "closest": cnt.closest, "shadow": cnt.shadow, "tests": cnt.tests, "rand_draws": cnt.draws}
 

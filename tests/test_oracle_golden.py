@@ -11,7 +11,7 @@ import oracle_lib
 from raytracer_amd import scenes
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("probe_"))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith(("probe_", "fullsize")))
 
 
 def load_case(path):
@@ -29,6 +29,23 @@ def test_oracle_matches_reference_golden(path):
     assert np.array_equal(em.view(np.uint32), z["emission"].view(np.uint32)), "emission buffer is not bit-identical"
     assert [cnt[k] for k in ("primary", "closest", "shadow", "tests", "rand_draws")] == [int(v) for v in z["counters"]]
     assert np.array_equal(oracle_lib.camera(sc, W, H).view(np.uint32), z["camera"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["C1", "C2"])
+def test_oracle_matches_reference_at_full_size(name):
+    """BASELINE.json configs C1 / C2 of DEFAULT-4: the port's whole frame against the hashes and tallies of the real
+    reference's frame (tests/golden/make_fullsize.py; SURVEY.md Appendix C: 572aa677 / 10 710 164 and 82bdc0e9 / 135 900 201)."""
+    import hashlib
+    with open(os.path.join(GOLDEN, "fullsize_hashes.json")) as fh:
+        g = json.load(fh)[name]
+    assert g["fnv1a32_body"] == {"C1": "572aa677", "C2": "82bdc0e9"}[name]
+    z = np.load(os.path.join(GOLDEN, "fullsize.npz"))
+    W, H, samples, depth, seed = g["width"], g["height"], g["samples"], g["max_depth"], g["seed_base"]
+    rgb, em, cnt = oracle_lib.render(scenes.default4(), W, H, samples, depth, seed, threads=8)
+    assert np.array_equal(rgb[::g["row_step"]], z[name + "_rows"])
+    assert np.array_equal(em[::g["row_step"]].view(np.uint32), z[name + "_emission_rows"].view(np.uint32))
+    assert hashlib.sha256(rgb.tobytes()).hexdigest() == g["sha256_body"]
+    assert {k: cnt[k] for k in g["counters"]} == g["counters"]
 
 
 def test_oracle_is_thread_count_and_band_independent():

@@ -25,3 +25,4 @@ run pmc_c --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F3
 run pmc_d --pmc FETCH_SIZE || exit 1
 run pmc_e --pmc WRITE_SIZE || exit 1
 find "$OUT" -name "*.csv" | head -40
+# per-frame totals for bench.py's roofline object (profiles/pmc_<workload>.json): tools/pmc_frame.py <tag> <workload>
