@@ -394,10 +394,12 @@ __device__ __forceinline__ bool hittable_hit(float4 r0, float4 r1, v3 ro, v3 rd,
 struct Hit { v3 position, normal; int material; };
 
 // position / normal / material of hittable `idx` at distance `dist` (sphere.h:46-49, plane.h:24-26, cube.h:28-46)
+// (SPHERES_ONLY: the scene holds nothing else, rt_abi.cpp's `nonsphere`)
+template <bool SPHERES_ONLY = false>
 __device__ __forceinline__ Hit hit_record(const SceneLds& sc, int idx, v3 ro, v3 rd, float dist)
 {
     float4 r0 = sc.hrec[2 * idx], r1 = sc.hrec[2 * idx + 1];
-    int type = rec_type(r1);
+    int type = SPHERES_ONLY ? (int)T_SPHERE : rec_type(r1);
     Hit h;
     h.material = rec_material(r1);
     v3 a = mk(r0.x, r0.y, r0.z);
@@ -741,9 +743,9 @@ __device__ __forceinline__ void wavelist_offer(WaveList& wl, int i, bool wanted)
 
 // closest_hit / closest_hit_primary over a candidate list
 template <bool HAS_NONSPHERE, bool PRIMARY>
-__device__ __forceinline__ int closest_hit_listed(const SceneLds& sc, const WaveList& wl, v3 ro, v3 rd, float& best)
+__device__ __forceinline__ int closest_hit_listed(const SceneLds& sc, const WaveList& wl, v3 ro, v3 rd, float& best, float fa_known = -1.0f)
 {
-    float fa = 4.0f * dot(rd, rd);
+    float fa = fa_known >= 0.0f ? fa_known : 4.0f * dot(rd, rd);
     v3 inv = mk(0, 0, 0);
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     best = 3.402823466e+38f;
@@ -803,6 +805,78 @@ __device__ __forceinline__ float light_intensity_listed(const SceneLds& sc, cons
         if (intens > intensity) {
             bool occluded = (type == L_DIR) ? any_hit_listed<HAS_NONSPHERE, false>(sc, wl, position, l, 0.0f)
                                             : any_hit_listed<HAS_NONSPHERE, true>(sc, wl, position, l, dist);
+            if (!occluded) intensity = intens;
+        }
+    }
+    return intensity;
+}
+
+// The same queries over a candidate list of at most RT_SMALL_LIST hittables whose records sit in scalar registers (the list is
+// the wave's, so its records are wave-uniform): what most waves of a frame have -- the ground, one sphere -- without a
+// register read, a scalar load and a wait per candidate and ray.  List order, same arithmetic.
+#ifndef RT_SMALL_LIST
+#define RT_SMALL_LIST 2
+#endif
+struct SmallList { float4 r0[RT_SMALL_LIST], r1[RT_SMALL_LIST]; int idx[RT_SMALL_LIST]; int n; };
+
+template <bool HAS_NONSPHERE, bool PRIMARY>
+__device__ __forceinline__ void smalllist_load(const SceneLds& sc, const WaveList& wl, SmallList& sl)
+{
+    sl.n = wl.n;
+#pragma unroll
+    for (int j = 0; j < RT_SMALL_LIST; ++j) {
+        const int i = j < wl.n ? __builtin_amdgcn_readlane(wl.items, j) : 0;
+        sl.idx[j] = i;
+        if (PRIMARY && !HAS_NONSPHERE) {
+            f32x4 p = sc.kprim[i];
+            sl.r0[j] = make_float4(p.x, p.y, p.z, p.w); sl.r1[j] = sl.r0[j];
+        } else {
+            sl.r0[j] = sc.urec(2 * i); sl.r1[j] = sc.urec(2 * i + 1);
+        }
+    }
+}
+
+template <bool HAS_NONSPHERE, bool PRIMARY>
+__device__ __forceinline__ int closest_hit_small(const SmallList& sl, v3 ro, v3 rd, float fa, float& best)
+{
+    v3 inv = mk(0, 0, 0);
+    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    best = 3.402823466e+38f;
+    int bi = -1;
+#pragma unroll
+    for (int j = 0; j < RT_SMALL_LIST; ++j) {
+        if (j < sl.n) {
+            float t;
+            bool hit;
+            if (PRIMARY && !HAS_NONSPHERE) hit = sphere_hit_oc(mk(sl.r0[j].x, sl.r0[j].y, sl.r0[j].z), sl.r0[j].w, rd, fa, t);
+            else                           hit = hittable_hit<HAS_NONSPHERE>(sl.r0[j], sl.r1[j], ro, rd, fa, inv, t);
+            if (hit && !(t >= best)) { best = t; bi = sl.idx[j]; }
+        }
+    }
+    return bi;
+}
+
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ float light_intensity_small(const SceneLds& sc, const SmallList& sl, v3 position, v3 normal)
+{
+    float intensity = 0.085f;
+    for (int i = 0; i < sc.n_lights; ++i) {
+        int type; float dist;
+        v3 l = light_direction(sc, i, position, type, dist);
+        float d = dot(normal, l);
+        float intens = d > 0 ? d : 0;
+        if (intens > intensity) {
+            bool occluded = false;
+            if (sl.n > 0) {
+                float fa = 4.0f * dot(l, l);
+                v3 inv = mk(0, 0, 0);
+                if (HAS_NONSPHERE) inv = mk(1.0f / l.x, 1.0f / l.y, 1.0f / l.z);
+#pragma unroll
+                for (int j = 0; j < RT_SMALL_LIST; ++j)
+                    if (j < sl.n && !occluded)
+                        occluded = (type == L_DIR) ? occluder_hit<HAS_NONSPHERE, false, false>(sl.r0[j], sl.r1[j], position, l, fa, inv, 0.0f)
+                                                   : occluder_hit<HAS_NONSPHERE, false, true>(sl.r0[j], sl.r1[j], position, l, fa, inv, dist);
+            }
             if (!occluded) intensity = intens;
         }
     }

@@ -14,6 +14,7 @@
 //   tile_pack / deinterleave / probe / debug kernels.
 #include "rt_device.hpp"
 #include "rt_launch.h"
+#include <type_traits>
 
 namespace rt {
 
@@ -99,7 +100,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
                 color = mk(w + a * 0.2f, w + a * 0.3f, w + a * 0.8f) * mult;
                 emission = mk(0, 0, 0); strength = 0.0f;
             } else {
-                Hit h = hit_record(sc, bi, ro, rd, dist);
+                Hit h = hit_record<!HAS_NONSPHERE>(sc, bi, ro, rd, dist);
                 v3 offPosition = h.position + h.normal * 0.005f;                 // renderer.h:55
                 if (COUNT) ++cnt.shaded;
                 float intensity = (listed_query && sc.cl_noccl >= 0)
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
                 int bi = closest_hit_listed<HAS_NONSPHERE, true>(sc, prim, origin, rd, dist);
                 const bool hit = mine && bi >= 0;
                 v3 pos = mk(0, 0, 0);
-                if (hit) { Hit h = hit_record(sc, bi, origin, rd, dist); pos = h.position + h.normal * 0.005f; }
+                if (hit) { Hit h = hit_record<!HAS_NONSPHERE>(sc, bi, origin, rd, dist); pos = h.position + h.normal * 0.005f; }
                 for (int j = 0; j < sc.n_lights; ++j) {
                     int type; float ldist;
                     v3 l = light_direction(sc, j, pos, type, ldist);
@@ -624,46 +625,66 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
     const bool culled = CULL && !prim.full && !occl.full;
     if (!mine) return;
 
+    // the four directions and 4 * dot(d, d) of each (`a` of sphere.h:17,24's quadratic) are the pixel's constants: in
+    // registers for all samples
+    v3 dk[4]; float fak[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        dk[k] = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+        fak[k] = 4.0f * dot(dk[k], dk[k]);
+    }
     v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0);
     float acc_st = 0.0f;
-    for (int s = 0; s < a.samples; ++s) {
-        v3 res_color = mk(0, 0, 0), res_em = mk(0, 0, 0);
-        float res_st = 0.0f;
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {                                        // renderer.h:167-195
-            v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
-            float dist;
-            int bi = culled ? closest_hit_listed<HAS_NONSPHERE, true>(sc, prim, origin, rd, dist)
-                            : primary_closest<HAS_NONSPHERE, RT_DIRECT_BATCH>(sc, origin, rd, dist);
-            v3 color, em = mk(0, 0, 0);
-            float st = 0.0f;
-            if (bi < 0) {                                                    // renderer.h:47-49
-                float aa = (rd.y + 1.0f) * 0.5f;
-                float w = 1.0f - aa;
-                color = mk(w + aa * 0.2f, w + aa * 0.3f, w + aa * 0.8f) * 1.0f;
-            } else {
-                Hit h = hit_record(sc, bi, origin, rd, dist);
-                v3 offPosition = h.position + h.normal * 0.005f;             // renderer.h:55
-                float intensity = culled ? light_intensity_listed<HAS_NONSPHERE>(sc, occl, offPosition, h.normal)
-                                         : light_intensity<HAS_NONSPHERE, false, true, RT_DIRECT_BATCH>(sc, offPosition, h.normal, none);
-                const float* m = sc.mats + 10 * h.material;
-                color = (mk(m[0], m[1], m[2]) * intensity) * 1.0f;           // renderer.h:64
-                if (EMISSION) { em = mk(m[6], m[7], m[8]); st = m[9]; }
+    // MODE 0: every query over the scene; 1: over the wave's candidate lists; 2: both lists hold at most RT_SMALL_LIST hittables,
+    // whose records stay in scalar registers
+    auto samples = [&](auto mode) {
+        constexpr int MODE = decltype(mode)::value;
+        SmallList sp, so;
+        if (MODE == 2) { smalllist_load<HAS_NONSPHERE, true>(sc, prim, sp); smalllist_load<HAS_NONSPHERE, false>(sc, occl, so); }
+        for (int s = 0; s < a.samples; ++s) {
+            v3 res_color = mk(0, 0, 0), res_em = mk(0, 0, 0);
+            float res_st = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                    // renderer.h:167-195
+                const v3 rd = dk[k];
+                float dist;
+                int bi = MODE == 2 ? closest_hit_small<HAS_NONSPHERE, true>(sp, origin, rd, fak[k], dist)
+                       : MODE == 1 ? closest_hit_listed<HAS_NONSPHERE, true>(sc, prim, origin, rd, dist, fak[k])
+                                   : primary_closest<HAS_NONSPHERE, RT_DIRECT_BATCH>(sc, origin, rd, dist);
+                v3 color, em = mk(0, 0, 0);
+                float st = 0.0f;
+                if (bi < 0) {                                                // renderer.h:47-49
+                    float aa = (rd.y + 1.0f) * 0.5f;
+                    float w = 1.0f - aa;
+                    color = mk(w + aa * 0.2f, w + aa * 0.3f, w + aa * 0.8f) * 1.0f;
+                } else {
+                    Hit h = hit_record<!HAS_NONSPHERE>(sc, bi, origin, rd, dist);
+                    v3 offPosition = h.position + h.normal * 0.005f;         // renderer.h:55
+                    float intensity = MODE == 2 ? light_intensity_small<HAS_NONSPHERE>(sc, so, offPosition, h.normal)
+                                    : MODE == 1 ? light_intensity_listed<HAS_NONSPHERE>(sc, occl, offPosition, h.normal)
+                                                : light_intensity<HAS_NONSPHERE, false, true, RT_DIRECT_BATCH>(sc, offPosition, h.normal, none);
+                    const float* m = sc.mats + 10 * h.material;
+                    color = (mk(m[0], m[1], m[2]) * intensity) * 1.0f;       // renderer.h:64
+                    if (EMISSION) { em = mk(m[6], m[7], m[8]); st = m[9]; }
+                }
+                res_color = res_color + color;                               // renderer.h:169, maxDepth == 1
+                if (EMISSION) {
+                    res_em = res_em + em;
+                    res_st = (k == 0) ? st : gmax(res_st, st);
+                }
             }
-            res_color = res_color + color;                                   // renderer.h:169, maxDepth == 1
+            res_color = res_color * 0.25f;
+            acc_color = acc_color + mk(clamp01(res_color.x), clamp01(res_color.y), clamp01(res_color.z));   // main.cpp:313
             if (EMISSION) {
-                res_em = res_em + em;
-                res_st = (k == 0) ? st : gmax(res_st, st);
+                res_em = res_em * 0.25f;
+                acc_em = acc_em + mk(clamp01(res_em.x), clamp01(res_em.y), clamp01(res_em.z));
+                acc_st += res_st;
             }
         }
-        res_color = res_color * 0.25f;
-        acc_color = acc_color + mk(clamp01(res_color.x), clamp01(res_color.y), clamp01(res_color.z));   // main.cpp:313
-        if (EMISSION) {
-            res_em = res_em * 0.25f;
-            acc_em = acc_em + mk(clamp01(res_em.x), clamp01(res_em.y), clamp01(res_em.z));
-            acc_st += res_st;
-        }
-    }
+    };
+    if (culled && prim.n <= RT_SMALL_LIST && occl.n <= RT_SMALL_LIST) samples(std::integral_constant<int, 2>());
+    else if (culled) samples(std::integral_constant<int, 1>());
+    else        samples(std::integral_constant<int, 0>());
     const float n = (float)a.samples;
     if (a.rgb) {                                                             // main.cpp:318 -> structs.h:12-17
         a.rgb[o * 3 + 0] = quantise(acc_color.x / n);
@@ -900,7 +921,7 @@ __global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
             float dist;
             const int bi = closest_hit_ldslist<HAS_NONSPHERE>(sc, lp, nprim, origin, rd, dist);
             if (bi < 0) continue;
-            const Hit h = hit_record(sc, bi, origin, rd, dist);
+            const Hit h = hit_record<!HAS_NONSPHERE>(sc, bi, origin, rd, dist);
             const v3 pos = h.position + h.normal * 0.005f;
             for (int j = 0; j < sc.n_lights && fits; ++j) {
                 int type; float ldist;
