@@ -180,12 +180,17 @@ def main():
         local_rank = int(os.environ["RT_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # The band gather goes through the library's rt_gather_rows (RCCL on the consumer context's stream); torch.distributed
+    # only carries the communicator's unique id and the timing reductions, for which gloo does.  RT_BENCH_GATHER=torch:
+    # torch.distributed.gather instead (backend nccl = RCCL too; gloo for the one-GPU rehearsal).
+    gather_mode = os.environ.get("RT_BENCH_GATHER", "rt")
+    backend = os.environ.get("RT_BENCH_BACKEND", "gloo" if gather_mode == "rt" else "nccl")
     if world > 1:
-        backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    rdev = dev if backend == "nccl" else torch.device("cpu")       # where the reductions' tensors live
 
     scene_name, W, H, samples, depth = WORKLOADS[args.workload]
     scene = ra.scenes.BUILTIN[scene_name]()
@@ -195,6 +200,26 @@ def main():
     for r in rts:
         r.upload_scene(scene)
     rt = rts[0]
+    consumer = ra.Renderer(local_rank)       # gathers and reassembles: a context (stream) of its own, beside the producers'
+    comm, gather_group = None, None
+    if world > 1 and gather_mode == "rt":
+        idt = torch.zeros(ra._abi.RT_COMM_ID_BYTES, dtype=torch.uint8, device=rdev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(ra.Renderer.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        ok, why = 1, ""
+        try:
+            comm = (consumer.comm_create(bytes(idt.cpu().numpy().tobytes()), rank, world), rank, world)
+        except Exception as e:          # (reported in the JSON line; every rank then takes the torch.distributed gather)
+            ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=rdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm:
+                consumer.comm_destroy(comm[0])
+            comm = None
+            gather_mode = "torch (rt_gather_rows unavailable: %s)" % (why or "another rank failed")
+            gather_group = dist.new_group(backend="nccl", device_id=dev) if backend != "nccl" else None
     cam = ra.camera35f(scene, W, H)
     rpr = bands.rows_per_rank(H, BAND_ROWS, world)
     seq = ra._abi.RT_FLAG_SEQUENCE if in_flight > 1 else 0          # several frames in flight on this GPU
@@ -210,7 +235,7 @@ def main():
             kernel_ms.append(rt.last_kernel_ms)
             device_ms.append(rt.last_device_ms)
 
-    pipe = FramePipeline(render, blocks, H, BAND_ROWS, rt, workers=in_flight)
+    pipe = FramePipeline(render, blocks, H, BAND_ROWS, consumer, group=gather_group, workers=in_flight, comm=comm)
 
     def sync():
         if world > 1:
@@ -218,7 +243,7 @@ def main():
         torch.cuda.synchronize()
 
     # warm-up: W frames one at a time, then every context once
-    solo = FramePipeline(render, blocks[:1], H, BAND_ROWS, rt, workers=1)
+    solo = FramePipeline(render, blocks[:1], H, BAND_ROWS, consumer, group=gather_group, workers=1, comm=comm)
     for _ in range(args.warmup):
         solo.run(1)
     if in_flight > 1:
@@ -257,7 +282,7 @@ def main():
     if in_flight == 1:                       # the timed frames themselves ran one at a time
         del kernel_ms[args.steps:], device_ms[args.steps:]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -276,10 +301,10 @@ def main():
     else:
         cnt = rt.render_rows(cam, pc, block, count=True)
     keys = ("primary", "closest", "shadow", "tests", "rand_draws", "shaded")
-    tv = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device=dev)
+    tv = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device=rdev)
     local_flops = algorithmic_flops(cnt, scene, W * p.rows, samples)
     # duration of one frame's render kernels when they do not overlap with another frame's
-    lf = torch.tensor([local_flops, float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
+    lf = torch.tensor([local_flops, float(np.mean(kernel_ms))], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tv)
         mx = lf.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -328,7 +353,8 @@ def main():
             "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp": samples, "max_depth": depth,
-                       "seed_base": seed, "parallelism": "cyclic %d-row bands over %d GPU(s), RCCL gather to rank 0" % (BAND_ROWS, world),
+                       "seed_base": seed, "parallelism": "cyclic %d-row bands over %d GPU(s), gather to rank 0: %s" % (
+                           BAND_ROWS, world, "none (one rank)" if world == 1 else "rt_gather_rows (RCCL send/recv group)" if comm else "torch.distributed.gather (%s; %s)" % (backend, gather_mode)),
                        "frames_in_flight": in_flight, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "frame_latency_ms": round(float(np.median(latency_ms)), 3),
             "rays": {"primary": tot["primary"], "secondary": tot["closest"] - tot["primary"], "shadow": tot["shadow"],
@@ -346,9 +372,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(scene, W, H, samples, depth, count_rays)
         print(json.dumps(line), flush=True)
         if verified is not None and not verified["identical"]:
-            for r in rts:
-                r.close()
             raise SystemExit("bench.py: the timed frame differs from the CPU oracle in %d pixels" % verified["differing_pixels"])
+    if comm:
+        consumer.comm_destroy(comm[0])
+    consumer.close()
     for r in rts:
         r.close()
     if world > 1:

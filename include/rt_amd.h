@@ -31,7 +31,8 @@ typedef enum {
                                   max_depth above RT_MAX_DEPTH, scene larger than the LDS staging budget     */
     RT_ERR_NO_SCENE     = -6,  /* rt_render_rows before rt_upload_scene                                      */
     RT_ERR_DEVICE_FAULT = -7,  /* the kernel reported an internal bound violation (bounce stack overflow)    */
-    RT_ERR_TOO_LARGE    = -8   /* rt_render_rows_static: rows * width above RT_STATIC_MAX_PIXELS              */
+    RT_ERR_TOO_LARGE    = -8,  /* rt_render_rows_static: rows * width above RT_STATIC_MAX_PIXELS              */
+    RT_ERR_RCCL         = -9   /* librccl could not be loaded, or an RCCL call failed; rt_last_rccl_error()   */
 } rt_status;
 
 enum { RT_SPHERE = 0, RT_PLANE = 1, RT_CUBE = 2 };        /* reference src/hittables/{sphere,plane,cube}.h   */
@@ -166,6 +167,39 @@ int rt_probe_max_depth(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* pa
  * height*width*bytes_per_pixel.  Both device pointers on the context's GPU. */
 int rt_deinterleave_bands(rt_ctx* ctx, const void* gathered, void* frame_out, int32_t width, int32_t height,
                           int32_t bytes_per_pixel, int32_t band_rows, int32_t nranks, int32_t rows_per_rank);
+
+/* Multi-GPU: the gather of the ranks' band blocks to rank 0 over RCCL (xGMI), one process per GPU.  Replaces the
+ * consumer side of the reference's tile transport: workers LPUSH their tiles, the main thread RPOPs and recomposes
+ * them (src/redis.h:27-48, src/main.cpp:322-326, 375-395); the reference has no collective of its own.
+ *
+ * rt_gather_rows: every rank calls it with its packed block (rt_render_rows output for row0 = rank*band_rows,
+ * band_rows, band_stride = nranks*band_rows; rows_per_rank*width*bytes_per_pixel bytes, the same size on every rank);
+ * one group of ncclSend (every rank -> 0) / ncclRecv (rank 0 <- every rank) on the context's stream delivers them
+ * into gathered_on_rank0 (nranks blocks, rank-major), and rank 0 reassembles frame_on_rank0 (height*width*
+ * bytes_per_pixel; NULL: leave the blocks as gathered).  nccl_comm: the caller's ncclComm_t for these ranks on these
+ * GPUs (one made by rt_comm_create, or its own); NULL with nranks == 1 (the block is reassembled in place, no RCCL).
+ * Device pointers on the context's GPU.  Synchronous: on return my_block may be rendered into again and the frame is
+ * complete.  Ranks must issue their gathers in the same order.  A communicator serves one gather at a time.
+ *
+ * rt_comm_unique_id / rt_comm_create / rt_comm_destroy: a communicator without linking RCCL into the host --
+ * ncclGetUniqueId on one rank, the RT_COMM_ID_BYTES carried to the others by whatever the host has (a pipe, MPI,
+ * torch.distributed), ncclCommInitRank on the context's GPU.  librccl is loaded when one of these is first called. */
+#define RT_COMM_ID_BYTES 128
+int  rt_comm_unique_id(unsigned char* id /* RT_COMM_ID_BYTES */);
+int  rt_comm_create(void** nccl_comm_out, rt_ctx* ctx, const unsigned char* id, int32_t rank, int32_t nranks);
+void rt_comm_destroy(void* nccl_comm);
+int  rt_gather_rows(rt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t nranks, const void* my_block, void* gathered_on_rank0,
+                    void* frame_on_rank0, int32_t width, int32_t height, int32_t bytes_per_pixel, int32_t band_rows,
+                    int32_t rows_per_rank);
+int  rt_last_rccl_error(const rt_ctx* ctx);          /* ncclResult_t of the last failing RCCL call of the context */
+
+/* One frame over the ranks of a job, for hosts that hold no device memory of their own (the C++ host of
+ * raytracer_amd/host): renders this rank's cyclic band_rows-row bands of the params->width x params->height frame
+ * (params->row0 / rows / band_* are ignored), gathers them with rt_gather_rows and leaves the frame's `pixel` bytes in
+ * rgb_out_rank0 (height*width*3, host or device) on rank 0.  What src/main.cpp:275-395 does with a thread pool and a
+ * Redis list, over GPUs.  The context keeps the band block and the gather buffer between calls. */
+int  rt_render_gather(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* params, void* nccl_comm, int32_t rank, int32_t nranks,
+                      int32_t band_rows, uint8_t* rgb_out_rank0);
 
 /* Tile streaming: replaces the producer side of the reference's Redis tile list (src/main.cpp:283-326 pushing through
  * Redis::SendImage, src/redis.h:27-36).  The frame is rendered in chunks of whole tile rows; after each chunk every

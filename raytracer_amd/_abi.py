@@ -17,10 +17,13 @@ RT_FLAG_SINGLE_KERNEL = 4
 RT_FLAG_FORCE_SAMPLE_PARALLEL = 8
 RT_FLAG_SEQUENCE = 16
 RT_FLAG_RAYS_LISTED = 32
+RT_COMM_ID_BYTES = 128
+RT_ERR_RCCL = -9
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_render_rows_static", "rt_render_tiles", "rt_probe_max_depth",
-    "rt_deinterleave_bands", "rt_last_kernel_ms", "rt_last_device_ms", "rt_last_hip_error", "rt_strerror",
+    "rt_deinterleave_bands", "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy", "rt_gather_rows", "rt_render_gather", "rt_last_rccl_error",
+    "rt_last_kernel_ms", "rt_last_device_ms", "rt_last_hip_error", "rt_strerror",
     "rt_debug_rand", "rt_debug_quantise", "rt_debug_intersect",
 ]
 
@@ -54,7 +57,7 @@ class Counters(ctypes.Structure):
 class RtError(RuntimeError):
     def __init__(self, status, what, hip=0):
         self.status, self.hip = status, hip
-        super().__init__("%s failed: %s (status %d, hip error %d)" % (what, _strerror(status), status, hip))
+        super().__init__("%s failed: %s (status %d, %s error %d)" % (what, _strerror(status), status, "rccl" if status == -9 else "hip", hip))
 
 
 _lib = None
@@ -84,6 +87,13 @@ def load():
     lib.rt_probe_max_depth.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), vp]
     lib.rt_render_tiles.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), i32, i32, TILE_SINK, vp]
     lib.rt_deinterleave_bands.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32]
+    lib.rt_comm_unique_id.argtypes = [vp]
+    lib.rt_comm_create.argtypes = [ctypes.POINTER(vp), vp, vp, i32, i32]
+    lib.rt_comm_destroy.argtypes = [vp]
+    lib.rt_comm_destroy.restype = None
+    lib.rt_gather_rows.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32]
+    lib.rt_last_rccl_error.argtypes = [vp]
+    lib.rt_render_gather.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), vp, i32, i32, i32, vp]
     lib.rt_last_kernel_ms.argtypes = [vp]
     lib.rt_last_kernel_ms.restype = ctypes.c_float
     lib.rt_last_device_ms.argtypes = [vp]

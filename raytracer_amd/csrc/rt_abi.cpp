@@ -5,6 +5,9 @@
 #include "rt_launch.h"
 #include "../host/camera.h"
 
+#include <rccl/rccl.h>      // types and prototypes only: the library is bound with dlopen (see rccl() below)
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -40,6 +43,7 @@ struct rt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, ev_list = nullptr, ev_gen = nullptr;
     float last_ms = 0.0f, last_total_ms = 0.0f;
     int last_hip = 0;
+    int last_rccl = 0;
 
     // uploaded scene
     bool has_scene = false;
@@ -67,6 +71,7 @@ struct rt_ctx {
     // pixel classes: keys (u16 per pixel) | pixel list (u32 per pixel) | histogram + cursor (2 * RT_MAX_KEYS u32)
     void* d_classes = nullptr; size_t classes_bytes = 0;
     void* d_tiles = nullptr; size_t tiles_bytes = 0;   // rt_render_tiles: chunk rows + tile records
+    void* d_gather = nullptr; size_t gather_bytes = 0; // rt_render_gather: band block | gather buffer | frame
     void* d_heavy = nullptr; size_t heavy_bytes = 0;   // sample-parallel pixels: count | records | generator states
     bool any_bounce = false;             // some material has reflection > 0 or refraction > 0
 };
@@ -216,6 +221,7 @@ const char* rt_strerror(int status)
     case RT_ERR_UNSUPPORTED:  return "unsupported (reflection > 1, max_depth > RT_MAX_DEPTH or scene too large)";
     case RT_ERR_NO_SCENE:     return "no scene uploaded";
     case RT_ERR_DEVICE_FAULT: return "device reported a bounce-stack overflow";
+    case RT_ERR_RCCL:         return "RCCL is not loadable or one of its calls failed (see rt_last_rccl_error)";
     case RT_ERR_TOO_LARGE:    return "rt_render_rows_static: rows * width exceeds RT_STATIC_MAX_PIXELS (the static scratch array holds no more)";
     default:                  return "unknown status";
     }
@@ -285,6 +291,7 @@ void rt_destroy(rt_ctx* ctx)
     if (ctx->d_classes) (void)hipFree(ctx->d_classes);
     if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
+    if (ctx->d_gather) (void)hipFree(ctx->d_gather);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -689,19 +696,199 @@ int rt_probe_max_depth(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
     return fault ? RT_ERR_DEVICE_FAULT : RT_OK;
 }
 
+// every row of every band must exist in its rank's block of rows_per_rank rows: band b is rank b % nranks' band
+// b / nranks (the last band of the frame may be short, an earlier full band of another rank then needs the larger index)
+static bool blocks_hold_frame(int height, int band_rows, int nranks, int rows_per_rank)
+{
+    const int nbands = (height + band_rows - 1) / band_rows;
+    for (int b = nbands - 1; b >= 0 && b >= nbands - nranks; --b) {          // the last band of each rank
+        const int rows = (b == nbands - 1) ? height - b * band_rows : band_rows;
+        if ((b / nranks) * band_rows + rows > rows_per_rank) return false;
+    }
+    return true;
+}
+
 int rt_deinterleave_bands(rt_ctx* ctx, const void* gathered, void* frame_out, int32_t width, int32_t height,
                           int32_t bytes_per_pixel, int32_t band_rows, int32_t nranks, int32_t rows_per_rank)
 {
     if (!ctx || !gathered || !frame_out) return RT_ERR_INVALID_ARG;
     if (width <= 0 || height <= 0 || bytes_per_pixel <= 0 || band_rows <= 0 || nranks <= 0 || rows_per_rank <= 0) return RT_ERR_INVALID_ARG;
-    // the last frame row must exist in its rank's block
-    const int last = height - 1, band = last / band_rows;
-    if ((band / nranks) * band_rows + (last % band_rows) >= rows_per_rank) return RT_ERR_INVALID_ARG;
+    if (!blocks_hold_frame(height, band_rows, nranks, rows_per_rank)) return RT_ERR_INVALID_ARG;
     if (!is_device_pointer(gathered) || !is_device_pointer(frame_out)) return RT_ERR_INVALID_ARG;
     DeviceGuard g(ctx->device);
     if (!g.ok) return RT_ERR_NO_DEVICE;
     HIP_TRY(ctx, rt_launch_deinterleave(gathered, frame_out, width * bytes_per_pixel, height, band_rows, nranks, rows_per_rank, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+// ---- the band gather over RCCL (include/rt_amd.h "multi-GPU") --------------------------------------------------
+// RCCL is bound at run time, on the first call that needs it: a one-GPU caller never loads it, and a process that has
+// loaded one already (torch brings its own) keeps using that one.
+}  // extern "C"
+
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+const Rccl& rccl()
+{
+    std::call_once(g_rccl_once, [] {
+        Rccl& r = g_rccl;
+        for (const char* name : { "librccl.so.1", "librccl.so" }) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);      // one that the process has already
+            if (r.lib) break;
+        }
+        for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+            if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!r.lib) return;
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+        r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
+        r.Recv = (decltype(r.Recv))dlsym(r.lib, "ncclRecv");
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
+    });
+    return g_rccl;
+}
+}  // namespace
+
+extern "C" {
+
+#define RCCL_TRY(ctx, expr)                                                                   \
+    do {                                                                                      \
+        ncclResult_t r__ = (expr);                                                            \
+        if (r__ != ncclSuccess) { if (ctx) (ctx)->last_rccl = (int)r__; return RT_ERR_RCCL; } \
+    } while (0)
+
+static_assert(RT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "rt_comm_unique_id hands out an ncclUniqueId");
+
+int rt_comm_unique_id(unsigned char* id)
+{
+    if (!id) return RT_ERR_INVALID_ARG;
+    const Rccl& r = rccl();
+    if (!r.ok) return RT_ERR_RCCL;
+    ncclUniqueId u;
+    if (r.GetUniqueId(&u) != ncclSuccess) return RT_ERR_RCCL;
+    std::memcpy(id, u.internal, RT_COMM_ID_BYTES);
+    return RT_OK;
+}
+
+int rt_comm_create(void** comm_out, rt_ctx* ctx, const unsigned char* id, int32_t rank, int32_t nranks)
+{
+    if (!comm_out) return RT_ERR_INVALID_ARG;
+    *comm_out = nullptr;
+    if (!ctx || !id || nranks <= 0 || rank < 0 || rank >= nranks) return RT_ERR_INVALID_ARG;
+    const Rccl& r = rccl();
+    if (!r.ok) return RT_ERR_RCCL;
+    DeviceGuard g(ctx->device);                       // the communicator belongs to the context's GPU
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, RT_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(ctx, r.CommInitRank(&comm, nranks, u, rank));
+    *comm_out = (void*)comm;
+    return RT_OK;
+}
+
+void rt_comm_destroy(void* comm)
+{
+    if (comm && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)comm);
+}
+
+int rt_last_rccl_error(const rt_ctx* ctx) { return ctx ? ctx->last_rccl : 0; }
+
+int rt_gather_rows(rt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t nranks, const void* my_block, void* gathered_on_rank0,
+                   void* frame_on_rank0, int32_t width, int32_t height, int32_t bytes_per_pixel, int32_t band_rows, int32_t rows_per_rank)
+{
+    if (!ctx || !my_block) return RT_ERR_INVALID_ARG;
+    if (width <= 0 || height <= 0 || bytes_per_pixel <= 0 || band_rows <= 0 || nranks <= 0 || rows_per_rank <= 0) return RT_ERR_INVALID_ARG;
+    if (rank < 0 || rank >= nranks) return RT_ERR_INVALID_ARG;
+    if (nranks > 1 && !nccl_comm) return RT_ERR_INVALID_ARG;
+    if (rank == 0 && nranks > 1 && !gathered_on_rank0) return RT_ERR_INVALID_ARG;
+    if (!blocks_hold_frame(height, band_rows, nranks, rows_per_rank)) return RT_ERR_INVALID_ARG;
+    if (!is_device_pointer(my_block)) return RT_ERR_INVALID_ARG;
+    if (rank == 0 && ((gathered_on_rank0 && !is_device_pointer(gathered_on_rank0)) || (frame_on_rank0 && !is_device_pointer(frame_on_rank0))))
+        return RT_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    const size_t block_bytes = (size_t)rows_per_rank * width * bytes_per_pixel;
+    const void* blocks = my_block;                    // one rank without a communicator: its block is the gather buffer
+    if (nccl_comm) {
+        // every rank sends its block to rank 0, which receives one block per rank (its own too): one group, so the
+        // transfers of all peers run side by side, one xGMI link each
+        const Rccl& r = rccl();
+        if (!r.ok) return RT_ERR_RCCL;
+        ncclComm_t comm = (ncclComm_t)nccl_comm;
+        if (rank == 0 && !gathered_on_rank0) return RT_ERR_INVALID_ARG;
+        RCCL_TRY(ctx, r.GroupStart());
+        ncclResult_t e = r.Send(my_block, block_bytes, ncclUint8, 0, comm, ctx->stream);
+        for (int peer = 0; rank == 0 && e == ncclSuccess && peer < nranks; ++peer)
+            e = r.Recv((unsigned char*)gathered_on_rank0 + (size_t)peer * block_bytes, block_bytes, ncclUint8, peer, comm, ctx->stream);
+        const ncclResult_t e2 = r.GroupEnd();
+        RCCL_TRY(ctx, e);
+        RCCL_TRY(ctx, e2);
+        blocks = gathered_on_rank0;
+    }
+    if (rank == 0 && frame_on_rank0)
+        HIP_TRY(ctx, rt_launch_deinterleave(blocks, frame_on_rank0, width * bytes_per_pixel, height, band_rows, nranks, rows_per_rank, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the block may be rendered into again, the frame read
+    return RT_OK;
+}
+
+int rt_render_gather(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* params, void* nccl_comm, int32_t rank, int32_t nranks,
+                     int32_t band_rows, uint8_t* rgb_out_rank0)
+{
+    if (!ctx || !cam || !params || band_rows <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return RT_ERR_INVALID_ARG;
+    if (nranks > 1 && !nccl_comm) return RT_ERR_INVALID_ARG;
+    if (rank == 0 && !rgb_out_rank0) return RT_ERR_INVALID_ARG;
+    if (params->width <= 0 || params->height <= 0) return RT_ERR_INVALID_ARG;
+    // this rank's cyclic bands of the whole frame (band b -> rank b % nranks), packed into a block of the size every rank uses
+    const int W = params->width, H = params->height;
+    const int nbands = (H + band_rows - 1) / band_rows;
+    const int rows_per_rank = ((nbands + nranks - 1) / nranks) * band_rows;
+    int my_rows = 0;
+    for (int b = rank; b < nbands; b += nranks) my_rows += (b == nbands - 1) ? H - b * band_rows : band_rows;
+    rt_params p = *params;
+    p.row0 = rank * band_rows; p.rows = my_rows; p.band_rows = band_rows; p.band_stride = band_rows * nranks;
+    p.flags &= ~(RT_FLAG_COUNT_LIKE_REFERENCE | RT_FLAG_COUNT_EXECUTED);
+    const size_t block_bytes = (size_t)rows_per_rank * W * 3, frame_bytes = (size_t)H * W * 3;
+    const bool out_dev = rank == 0 && is_device_pointer(rgb_out_rank0);
+    // block | (rank 0) gather buffer | (rank 0, host output) frame
+    const size_t need = block_bytes + (rank == 0 ? (size_t)nranks * block_bytes + (out_dev ? 0 : frame_bytes) : 0);
+    int rc = grow(ctx, &ctx->d_gather, &ctx->gather_bytes, need);
+    if (rc) return rc;
+    unsigned char* block = (unsigned char*)ctx->d_gather;
+    unsigned char* gathered = block + block_bytes;
+    unsigned char* frame = out_dev ? rgb_out_rank0 : gathered + (size_t)nranks * block_bytes;
+    if (my_rows > 0) {
+        rc = rt_render_rows(ctx, cam, &p, block, nullptr, nullptr);
+        if (rc != RT_OK) return rc;
+    }
+    rc = rt_gather_rows(ctx, nccl_comm, rank, nranks, block, rank == 0 ? gathered : nullptr, rank == 0 ? frame : nullptr, W, H, 3,
+                        band_rows, rows_per_rank);
+    if (rc != RT_OK) return rc;
+    if (rank == 0 && !out_dev) {
+        DeviceGuard g(ctx->device);
+        if (!g.ok) return RT_ERR_NO_DEVICE;
+        HIP_TRY(ctx, hipMemcpyAsync(rgb_out_rank0, frame, frame_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return RT_OK;
 }
 

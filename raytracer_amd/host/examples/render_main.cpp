@@ -6,6 +6,8 @@
 //   rt_render [--scene file] [--w 1024 --h 512 --samples 5 --depth 10 --seed-base 0] [--out output.ppm]
 //             [--emission out.f32] [--probe] [--speedup] [--tiles 16 [--chunk-rows 128]]
 //             [--frames 8 [--in-flight 4]]      frame k is seeded seed-base + 1000 k and written to <out>.<k>.ppm
+//             [--ranks N]                       one process per GPU (ranks 1..N-1 forked before anything touches a GPU), cyclic
+//                                               16-row bands, RCCL gather to rank 0 (GPU r = --device + r)
 #include "../renderer.h"
 
 #include "../lights/directionalLight.h"
@@ -18,12 +20,15 @@
 #include <cstring>
 #include <vector>
 
+#include <sys/wait.h>
+#include <unistd.h>
+
 int main(int argc, char** argv)
 {
     RenderSettings st;
     const char* scenePath = nullptr; const char* out = "output.ppm"; const char* outEm = nullptr;
     bool probe = false, speedup = false;
-    int tiles = 0, chunkRows = 0, frames = 0, inFlight = 4;
+    int tiles = 0, chunkRows = 0, frames = 0, inFlight = 4, ranks = 0;
     for (int i = 1; i < argc; ++i) {
         auto is = [&](const char* k) { return !std::strcmp(argv[i], k) && i + 1 < argc; };
         if      (is("--scene"))     scenePath = argv[++i];
@@ -39,9 +44,36 @@ int main(int argc, char** argv)
         else if (is("--chunk-rows")) chunkRows = std::atoi(argv[++i]);
         else if (is("--frames"))    frames = std::atoi(argv[++i]);
         else if (is("--in-flight")) inFlight = std::atoi(argv[++i]);
+        else if (is("--ranks"))     ranks = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--probe"))   probe = true;
         else if (!std::strcmp(argv[i], "--speedup")) speedup = true;
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+
+    // --ranks N: ranks 1 .. N-1 are forked here, before anything touches a GPU; rank 0 makes the communicator's id and
+    // hands it to them through pipes
+    int rank = 0;
+    unsigned char commId[RT_COMM_ID_BYTES] = { 0 };
+    std::vector<pid_t> kids;
+    if (ranks > 1) {
+        std::vector<int> rd((size_t)ranks, -1), wr((size_t)ranks, -1);
+        for (int r = 1; r < ranks; ++r) { int fd[2]; if (pipe(fd) != 0) { std::perror("pipe"); return 2; } rd[(size_t)r] = fd[0]; wr[(size_t)r] = fd[1]; }
+        for (int r = 1; r < ranks && rank == 0; ++r) {
+            pid_t pid = fork();
+            if (pid < 0) { std::perror("fork"); return 2; }
+            if (pid == 0) rank = r; else kids.push_back(pid);
+        }
+        if (rank == 0) {
+            int rc = rt_comm_unique_id(commId);
+            if (rc != RT_OK) { std::fprintf(stderr, "rt_comm_unique_id failed: %s\n", rt_strerror(rc)); std::memset(commId, 0, sizeof commId); }
+            for (int r = 1; r < ranks; ++r) { if (write(wr[(size_t)r], commId, sizeof commId) != (ssize_t)sizeof commId) std::perror("write"); close(wr[(size_t)r]); close(rd[(size_t)r]); }
+            if (rc != RT_OK) return 1;
+        } else {
+            for (int r = 1; r < ranks; ++r) { close(wr[(size_t)r]); if (r != rank) close(rd[(size_t)r]); }
+            if (read(rd[(size_t)rank], commId, sizeof commId) != (ssize_t)sizeof commId) { std::fprintf(stderr, "rank %d: no communicator id\n", rank); return 1; }
+            close(rd[(size_t)rank]);
+        }
+        st.device += rank;
     }
 
     LoadedScene loaded;
@@ -82,6 +114,18 @@ int main(int argc, char** argv)
     } else if (speedup) {
         double ms = RenderTimed(camera, world, lights, materials, st);
         if (ms < 0) rc = 1; else std::printf("Ended in: %lf\n", ms);                       // src/tests/speedUp.cpp:48
+    } else if (ranks > 0) {
+        // one frame (or --frames of the same frame, timed) over --ranks GPUs
+        std::vector<pixel> image(rank == 0 ? (size_t)st.width * st.height : 0);
+        double ms = 0.0;
+        int status = RenderImageRanks(camera, world, lights, materials, materialsCount, st, rank, ranks, commId,
+                                      rank == 0 ? image.data() : nullptr, frames > 0 ? frames : 1, &ms);
+        if (status != RT_OK) { std::fprintf(stderr, "rank %d: RenderImageRanks failed: %s\n", rank, rt_strerror(status)); rc = 1; }
+        else if (rank == 0) {
+            std::printf("Ended in: %lf ms per frame (%d ranks)\n", ms, ranks);
+            writePPM(out, image.data(), st.width, st.height);
+        }
+        for (pid_t pid : kids) { int wst = 0; if (waitpid(pid, &wst, 0) < 0 || !WIFEXITED(wst) || WEXITSTATUS(wst) != 0) rc = 1; }
     } else if (frames > 0) {
         // a sequence of frames, several in flight; delivered in order
         auto t0 = std::chrono::steady_clock::now();

@@ -117,6 +117,33 @@ inline int RenderImage(Camera& camera, Hittable* world, Light* lights, Material*
     return rc;
 }
 
+// One frame over `nranks` processes, one per GPU (this process is `rank`, on GPU settings.device): every rank renders
+// its cyclic 16-row bands, RCCL carries them to rank 0, which leaves the frame in image[width*height] -- the reference's
+// worker threads, Redis list and recompose loop (src/main.cpp:268-395) across GPUs.  commId: RT_COMM_ID_BYTES made by
+// rt_comm_unique_id() on one rank and carried to the others by the host (rt_render --ranks uses pipes).  image: rank 0.
+inline int RenderImageRanks(Camera& camera, Hittable* world, Light* lights, Material* materials, int materialsCount,
+                            const RenderSettings& settings, int rank, int nranks, const unsigned char* commId, pixel* image,
+                            int frames = 1, double* msPerFrame = nullptr)
+{
+    rt_host::Session s(world, lights, materials, materialsCount, settings.device);
+    if (s.status != RT_OK) return s.status;
+    void* comm = nullptr;
+    if (nranks > 1) {
+        int rc = rt_comm_create(&comm, s.ctx, commId, rank, nranks);
+        if (rc != RT_OK) return rc;
+    }
+    rt_camera35f cam;
+    rt_host::camera35(camera, cam);
+    rt_params p = rt_host::params(settings);
+    int rc = RT_OK;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < frames && rc == RT_OK; ++k)
+        rc = rt_render_gather(s.ctx, &cam, &p, comm, rank, nranks, 16, reinterpret_cast<uint8_t*>(image));
+    if (msPerFrame) *msPerFrame = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (frames > 0 ? frames : 1);
+    rt_comm_destroy(comm);
+    return rc;
+}
+
 // The producer side of the reference's tile list (src/main.cpp:283-340): every whole tileSize x tileSize tile of the frame
 // is handed to `send` twice, with the arguments the reference gives Redis::SendImage (src/redis.h:27) -- first the
 // `pixel` payload, then the `emissionPixel` payload -- and `progress` (if set) receives the percentage the reference

@@ -27,7 +27,7 @@ class FramePipeline:
     (Renderer.render_rows does).  blocks: [rows_per_rank, W, C] tensors, same shape on every rank, at least `workers`
     of them.  Not re-entrant: one run() at a time."""
 
-    def __init__(self, render, blocks, height, band_rows, renderer=None, group=None, workers=None):
+    def __init__(self, render, blocks, height, band_rows, renderer=None, group=None, workers=None, comm=None):
         if not blocks:
             raise ValueError("FramePipeline needs at least one band block")
         self.render = render
@@ -39,6 +39,10 @@ class FramePipeline:
         self.band_rows = band_rows
         self.renderer = renderer
         self.group = group
+        # comm = (ncclComm_t handle from Renderer.comm_create, rank, nranks): the gather goes through the library's
+        # rt_gather_rows on `renderer`'s stream (RCCL, no torch.distributed on the data path); None: torch.distributed
+        # (gloo in the CPU tests) or a single rank
+        self.comm = comm
         self._gathered = None
         self._frame = None
 
@@ -48,6 +52,8 @@ class FramePipeline:
         on = dist.is_initialized()
         nranks = dist.get_world_size(self.group) if on else 1
         rank = dist.get_rank(self.group) if on else 0
+        if self.comm is not None:
+            _, rank, nranks = self.comm
         b = self.blocks[0]
         if rank == 0 and self._frame is None:
             if nranks > 1:
@@ -101,7 +107,13 @@ class FramePipeline:
                 if failed:
                     raise failed[0]
                 block = self.blocks[slot]
-                if nranks == 1:
+                if self.comm is not None and nranks > 1:
+                    W = block.shape[1]
+                    bpp = block.element_size() * (block.shape[2] if block.dim() > 2 else 1)
+                    self.renderer.gather_rows(self.comm[0], rank, nranks, block, self._gathered, self._frame, W, self.height, bpp,
+                                              self.band_rows, block.shape[0])
+                    last = self._frame
+                elif nranks == 1:
                     last = bands.deinterleave(block.unsqueeze(0), self._frame, self.band_rows, 1, self.renderer)
                 else:
                     import torch.distributed as dist

@@ -70,7 +70,7 @@ class Renderer:
 
     def _check(self, rc, what):
         if rc != _abi.RT_OK:
-            raise _abi.RtError(rc, what, self._lib.rt_last_hip_error(self._h))
+            raise _abi.RtError(rc, what, self._lib.rt_last_rccl_error(self._h) if rc == _abi.RT_ERR_RCCL else self._lib.rt_last_hip_error(self._h))
 
     def upload_scene(self, scene: Scene):
         mats, htype, ha, hb, hr, hm, ltype, lv = (np.ascontiguousarray(a) for a in scene.arrays())
@@ -141,6 +141,35 @@ class Renderer:
     def deinterleave_bands(self, gathered, frame_out, width, height, bytes_per_pixel, band_rows, nranks, rows_per_rank):
         self._check(self._lib.rt_deinterleave_bands(self._h, _ptr(gathered), _ptr(frame_out), width, height, bytes_per_pixel,
                                                     band_rows, nranks, rows_per_rank), "rt_deinterleave_bands")
+
+    # multi-GPU: the band gather over RCCL (include/rt_amd.h rt_gather_rows); communicators are plain ncclComm_t handles
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId through the library (one rank calls it; the bytes go to the other ranks by any means)."""
+        buf = (ctypes.c_ubyte * _abi.RT_COMM_ID_BYTES)()
+        rc = _abi.load().rt_comm_unique_id(buf)
+        if rc != 0:
+            raise _abi.RtError(rc, "rt_comm_unique_id")
+        return bytes(buf)
+
+    def comm_create(self, unique_id, rank, nranks):
+        """ncclCommInitRank on this context's GPU.  -> communicator handle (int) for gather_rows / comm_destroy"""
+        if len(unique_id) != _abi.RT_COMM_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % _abi.RT_COMM_ID_BYTES)
+        comm = ctypes.c_void_p()
+        buf = (ctypes.c_ubyte * _abi.RT_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._lib.rt_comm_create(ctypes.byref(comm), self._h, buf, rank, nranks), "rt_comm_create")
+        return comm.value
+
+    def comm_destroy(self, comm):
+        if comm:
+            self._lib.rt_comm_destroy(ctypes.c_void_p(comm))
+
+    def gather_rows(self, comm, rank, nranks, block, gathered, frame_out, width, height, bytes_per_pixel, band_rows, rows_per_rank):
+        """rt_gather_rows: this rank's packed band block to rank 0 (grouped ncclSend / ncclRecv on the context's stream),
+        reassembled into frame_out there.  block / gathered / frame_out: device tensors (gathered, frame_out: rank 0)."""
+        self._check(self._lib.rt_gather_rows(self._h, ctypes.c_void_p(comm) if comm else None, rank, nranks, _ptr(block), _ptr(gathered),
+                                             _ptr(frame_out), width, height, bytes_per_pixel, band_rows, rows_per_rank), "rt_gather_rows")
 
     @property
     def last_kernel_ms(self):

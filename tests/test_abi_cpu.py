@@ -49,6 +49,15 @@ def test_host_only_validation():
     assert lib.rt_strerror(_abi.RT_ERR_SCENE).decode().startswith("malformed scene")
     assert lib.rt_render_rows(None, None, None, None, None, None) == _abi.RT_ERR_INVALID_ARG
     assert lib.rt_upload_scene(None, None) == _abi.RT_ERR_INVALID_ARG
+    # the multi-GPU entry points reject bad arguments before they touch RCCL or a GPU
+    assert lib.rt_gather_rows(None, None, 0, 1, None, None, None, 1, 1, 1, 1, 1) == _abi.RT_ERR_INVALID_ARG
+    assert lib.rt_comm_create(None, None, None, 0, 1) == _abi.RT_ERR_INVALID_ARG
+    comm = ctypes.c_void_p(123)
+    assert lib.rt_comm_create(ctypes.byref(comm), None, None, 0, 1) == _abi.RT_ERR_INVALID_ARG and comm.value is None
+    assert lib.rt_comm_unique_id(None) == _abi.RT_ERR_INVALID_ARG
+    lib.rt_comm_destroy(None)
+    assert lib.rt_last_rccl_error(None) == 0
+    assert b"RCCL" in lib.rt_strerror(_abi.RT_ERR_RCCL)
 
 
 def test_no_silent_cpu_fallback():

@@ -421,6 +421,46 @@ def test_frames_in_flight_equal_frames_one_at_a_time(rt):
         assert np.array_equal(got[k], want[k]), "frame %d" % k
 
 
+def test_gather_rows_over_rccl_single_rank(rt):
+    """rt_gather_rows with a real RCCL communicator of one rank: the rank's block goes through ncclSend / ncclRecv (to
+    and from itself) into the gather buffer and is reassembled; same bytes as the frame rendered whole.  (More ranks
+    need more GPUs: tests/test_bands_gloo.py covers the partition and the frame order with gloo.)"""
+    import torch
+    from raytracer_amd import _abi, bands
+    sc = scenes.default4()
+    W, H, samples, depth, band = 200, 90, 2, 10, 16
+    rt.upload_scene(sc)
+    want, _, _ = rt.render(W, H, samples, depth, 5)
+    cam = ra.camera35f(sc, W, H)
+    rpr = bands.rows_per_rank(H, band, 1)
+    block = torch.zeros((rpr, W, 3), dtype=torch.uint8, device="cuda:0")
+    gathered = torch.zeros((1, rpr, W, 3), dtype=torch.uint8, device="cuda:0")
+    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    rt.render_rows(cam, bands.band_params(rt, W, H, samples, depth, 5, band, 1, 0), block)
+    comm = rt.comm_create(ra.Renderer.comm_unique_id(), 0, 1)
+    try:
+        for _ in range(2):
+            frame.zero_()
+            rt.gather_rows(comm, 0, 1, block, gathered, frame, W, H, 3, band, rpr)
+            assert np.array_equal(frame.cpu().numpy(), want)
+        # no communicator, one rank: reassembled straight from the block
+        frame.zero_()
+        rt.gather_rows(None, 0, 1, block, None, frame, W, H, 3, band, rpr)
+        assert np.array_equal(frame.cpu().numpy(), want)
+        with pytest.raises(ra.RtError) as e:                     # two ranks need a communicator
+            rt.gather_rows(None, 0, 2, block, gathered, frame, W, H, 3, band, rpr)
+        assert e.value.status == _abi.RT_ERR_INVALID_ARG
+        with pytest.raises(ra.RtError) as e:                     # blocks too small for the frame (a short last band of
+            rt.gather_rows(comm, 0, 2, block, gathered, frame, W, 101, 3, 100, 1)     # one rank, a full band of the other)
+        assert e.value.status == _abi.RT_ERR_INVALID_ARG
+        with pytest.raises(ra.RtError) as e:
+            rt.deinterleave_bands(gathered, frame, W, 101, 3, 100, 2, 1)
+        assert e.value.status == _abi.RT_ERR_INVALID_ARG
+    finally:
+        rt.comm_destroy(comm)
+
+
 def test_probe_max_depth(rt, golden_dir):
     z = np.load(os.path.join(golden_dir, "probe_glass_mirror_128x64_d3_seed0.npz"))
     sc = scenes.Scene.from_text(bytes(z["scene"]).decode())

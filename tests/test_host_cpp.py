@@ -81,6 +81,20 @@ def test_cpp_driver_default_scene_matches_golden(golden_dir):
 
 
 @pytest.mark.gpu
+def test_cpp_driver_ranks_mode_matches_golden(golden_dir):
+    """--ranks 1: RenderImageRanks() -> rt_render_gather (band render, rt_gather_rows with a one-rank RCCL communicator,
+    reassembly) gives the golden frame.  More ranks fork one process per GPU: not runnable on a one-GPU box."""
+    z = np.load(os.path.join(golden_dir, "default4_256x128_s5_d10_seed1000.npz"))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.ppm")
+        r = subprocess.run([EXE, "--w", "256", "--h", "128", "--samples", "5", "--depth", "10", "--seed-base", "1000",
+                            "--out", out, "--ranks", "1", "--frames", "2"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "1 ranks" in r.stdout
+        assert np.array_equal(_read_ppm(out), z["rgb"])
+
+
+@pytest.mark.gpu
 def test_cpp_driver_scene_file_and_probe(golden_dir):
     z = np.load(os.path.join(golden_dir, "cube_128x64_s4_d10_seed0.npz"))
     with tempfile.TemporaryDirectory() as td:
