@@ -73,6 +73,7 @@ struct rt_ctx {
     void* d_tiles = nullptr; size_t tiles_bytes = 0;   // rt_render_tiles: chunk rows + tile records
     void* d_gather = nullptr; size_t gather_bytes = 0; // rt_render_gather: band block | gather buffer | frame
     void* d_heavy = nullptr; size_t heavy_bytes = 0;   // sample-parallel pixels: count | records | generator states
+    size_t heavy_pool_bytes = 0;                       // ... its stream pool (sized from the pixel list, rt_render_rows)
     bool any_bounce = false;             // some material has reflection > 0 or refraction > 0
 };
 
@@ -218,7 +219,7 @@ const char* rt_strerror(int status)
     case RT_ERR_NO_DEVICE:    return "no usable gfx950 device";
     case RT_ERR_HIP:          return "HIP runtime error (see rt_last_hip_error)";
     case RT_ERR_SCENE:        return "malformed scene (material index / hittable type / light type)";
-    case RT_ERR_UNSUPPORTED:  return "unsupported (reflection > 1, max_depth > RT_MAX_DEPTH or scene too large)";
+    case RT_ERR_UNSUPPORTED:  return "unsupported (reflection > 1, negative reflection / refraction, max_depth > RT_MAX_DEPTH or scene too large)";
     case RT_ERR_NO_SCENE:     return "no scene uploaded";
     case RT_ERR_DEVICE_FAULT: return "device reported a bounce-stack overflow";
     case RT_ERR_RCCL:         return "RCCL is not loadable or one of its calls failed (see rt_last_rccl_error)";
@@ -326,6 +327,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
         // reflection > 1 lets the multiplier grow: the reference's recursion is then bounded by nothing but depth
         // for reflections and by nothing at all through refractions (renderer.h:82,118)
         if (reflection > 1.0f || reflection != reflection || refraction != refraction) return RT_ERR_UNSUPPORTED;
+        // a negative reflection or refraction takes neither branch of renderer.h:74,93 and fails the `both zero` test of
+        // :128, so maxDepth stays 0 and AntiAliasing divides by it (:169): inf / NaN pixels in the reference.  The
+        // kernel pair keys such a material as direct (maxDepth 1): refused rather than rendered differently.
+        if (reflection < 0.0f || refraction < 0.0f) return RT_ERR_UNSUPPORTED;
         if (reflection > 0.0f && refraction > 0.0f) mixed = true;
         if (reflection > 0.0f || refraction > 0.0f) any_bounce = true;
     }
@@ -537,7 +542,15 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                 if (!coop && !rays && !no_alloc && p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
                     // records + a pool for the pixels' written-out rand() sequences
                     size_t cap = n_listed < RT_HEAVY_CAP ? n_listed : RT_HEAVY_CAP;
-                    const size_t pool_words = RT_HEAVY_TABLE_BYTES / 4;
+                    // the pool follows the list: 64 bytes per listed pixel and sample (a pixel that draws 8 numbers per
+                    // sample fills a quarter of that), between 16 MiB and RT_HEAVY_TABLE_BYTES; a full pool only means
+                    // that further long pixels stay serial.  Grown, never shrunk: a sequence of frames allocates once.
+                    size_t pool_bytes = (size_t)n_listed * (size_t)p->samples * 64;
+                    if (pool_bytes < ((size_t)16 << 20)) pool_bytes = (size_t)16 << 20;
+                    if (pool_bytes > RT_HEAVY_TABLE_BYTES) pool_bytes = RT_HEAVY_TABLE_BYTES;
+                    if (ctx->heavy_pool_bytes > pool_bytes) pool_bytes = ctx->heavy_pool_bytes;
+                    ctx->heavy_pool_bytes = pool_bytes;
+                    const size_t pool_words = pool_bytes / 4;
                     rc = grow(ctx, &ctx->d_heavy, &ctx->heavy_bytes, 16 + 4 * (pool_words + cap * (RT_HEAVY_REC_WORDS + 1)));
                     if (rc) return rc;
                     g2.heavy_count = (unsigned int*)(state + RT_DEV_HEAVY_AT);   // zeroed with the counters

@@ -82,7 +82,47 @@ class Scene:
             fh.write(self.to_text())
 
     @staticmethod
-    def from_text(text: str, name: str = "scene") -> "Scene":
+    def _table_row(s: "Scene", kw: str, line: str, scene_id: int) -> bool:
+        """A row of the reference's Postgres tables (src/postgres.h:183-228) in table-column order, VEC3 columns written
+        "(x, y, z)" as readVec3 (src/postgres.h:232-256) takes them; columns separated by blanks, '|' or ','.
+            material <id> (color) <roughness> <reflection> <refraction> (emission_color) <glow_strength>
+            sphere <id> (position) <radius> <material_id> <scene_id>
+            directional_light <id> (direction) <scene_id>
+        Rows of another scene are skipped (getWorld / getLights select by scene_id, src/postgres.h:88,113); material
+        indices are row order (getMaterials, src/postgres.h:66-77).  False: not such a row."""
+        if kw not in ("material", "sphere", "directional_light") or "(" not in line:
+            return False
+        cols, rest = [], line[len(kw):].replace("|", " ").replace("\t", " ")
+        while rest.strip(" ,"):
+            rest = rest.lstrip(" ,")
+            if rest[0] == "(":
+                end = rest.index(")")
+                parts = rest[1:end].split(",")
+                if len(parts) != 3:
+                    raise ValueError
+                cols.append(tuple(float(x) for x in parts))          # atof of each part
+                rest = rest[end + 1:]
+            else:
+                tok = rest.split(None, 1)[0].split(",", 1)[0]
+                if tok.endswith("::VEC3"):
+                    tok = tok[:-6]
+                cols.append(float(tok))
+                rest = rest[len(tok):]
+        shape = [isinstance(c, tuple) for c in cols]
+        if kw == "material" and shape == [False, True, False, False, False, True, False]:
+            s.materials.append(tuple(_f(x) for x in (*cols[1], cols[2], cols[3], cols[4], *cols[5], cols[6])))
+        elif kw == "sphere" and shape == [False, True, False, False, False]:
+            if int(cols[4]) == scene_id:
+                s.sphere(cols[1], cols[2], int(cols[3]))
+        elif kw == "directional_light" and shape == [False, True, False]:
+            if int(cols[2]) == scene_id:
+                s.dirlight(cols[1])
+        else:
+            raise ValueError
+        return True
+
+    @staticmethod
+    def from_text(text: str, name: str = "scene", scene_id: int = 0) -> "Scene":
         s = Scene(name=name)
         for ln, raw in enumerate(text.splitlines(), 1):
             line = raw.split("#", 1)[0].strip()
@@ -90,6 +130,8 @@ class Scene:
                 continue
             kw, *rest = line.split()
             try:
+                if Scene._table_row(s, kw, line.replace("'", "").replace("::VEC3", ""), scene_id):
+                    continue
                 v = [float(x) for x in rest]
                 if kw == "material":
                     if len(v) != 10:

@@ -552,6 +552,11 @@ def test_error_codes(rt):
     with pytest.raises(ra.RtError) as e:
         rt.upload_scene(hot)
     assert e.value.status == _abi.RT_ERR_UNSUPPORTED
+    for col in (4, 5):                                # negative reflection / refraction: inf / NaN pixels in the reference
+        neg = scenes.default4(); neg.materials[1] = neg.materials[1][:col] + (-0.25,) + neg.materials[1][col + 1:]
+        with pytest.raises(ra.RtError) as e:
+            rt.upload_scene(neg)
+        assert e.value.status == _abi.RT_ERR_UNSUPPORTED
     fresh = ra.Renderer(0)
     with pytest.raises(ra.RtError) as e:
         fresh.render(64, 64, 1, 5, cam=ra.camera35f(60.0, 64, 64))

@@ -95,6 +95,18 @@ def test_cpp_driver_ranks_mode_matches_golden(golden_dir):
 
 
 @pytest.mark.gpu
+def test_cpp_driver_reads_reference_table_rows(golden_dir):
+    """f2: LoadScene() reads rows of the reference's tables with "(x, y, z)" VEC3 columns (src/postgres.h:183-256)."""
+    z = np.load(os.path.join(golden_dir, "default4_256x128_s5_d10_seed1000.npz"))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.ppm")
+        r = subprocess.run([EXE, "--scene", os.path.join(ROOT, "scenes", "default4_tables.rtscene"), "--w", "256", "--h", "128",
+                            "--samples", "5", "--depth", "10", "--seed-base", "1000", "--out", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.array_equal(_read_ppm(out), z["rgb"])
+
+
+@pytest.mark.gpu
 def test_cpp_driver_scene_file_and_probe(golden_dir):
     z = np.load(os.path.join(golden_dir, "cube_128x64_s4_d10_seed0.npz"))
     with tempfile.TemporaryDirectory() as td:

@@ -116,3 +116,22 @@ def test_scene_text_round_trip():
         scenes.Scene.from_text("sphere 1 2 3\n")
     with pytest.raises(ValueError):
         scenes.Scene.from_text("torus 1 2 3\n")
+
+
+def test_scene_text_reads_rows_of_the_reference_tables():
+    """f2: rows of the reference's material / sphere / directional_light tables (src/postgres.h:183-228) with VEC3 columns
+    in readVec3's "(x, y, z)" syntax (src/postgres.h:232-256) load as the scene the reference builds from them."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = scenes.Scene.load(os.path.join(root, "scenes", "default4_tables.rtscene"))
+    b = scenes.default4()
+    assert (a.materials, a.hittables, a.lights) == (b.materials, b.hittables, b.lights)
+    # the reference's own INSERT syntax and a psql-style dump; rows of other scenes are skipped
+    c = scenes.Scene.from_text("material 0, '(0.8, 0.8, 0.0)'::VEC3, 0.0, 0.0, 0.0, '(0.0, 0.0, 0.0)'::VEC3, 0.0\n"
+                               "sphere 1 | (0,1,-4) | 1 | 0 | 0\nsphere 2 | (5,1,-4) | 1 | 0 | 3\n"
+                               "directional_light 0 (-0.25, -0.75, 0.45) 0\ndirectional_light 1 (1, 0, 0) 3\n")
+    assert c.materials == b.materials[:1] and len(c.hittables) == 1 and c.hittables[0][1] == (0.0, 1.0, -4.0) and c.lights == b.lights
+    assert len(scenes.Scene.from_text("sphere 2 (5,1,-4) 1 0 3\n", scene_id=3).hittables) == 1
+    for bad in ("sphere 1 (0, 1) 1 0 0\n", "material 0 (1, 1, 1) 0 0\n", "directional_light (0, 0, 1)\n"):
+        with pytest.raises(ValueError):
+            scenes.Scene.from_text(bad)
+
