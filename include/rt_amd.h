@@ -201,6 +201,17 @@ int  rt_last_rccl_error(const rt_ctx* ctx);          /* ncclResult_t of the last
 int  rt_render_gather(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* params, void* nccl_comm, int32_t rank, int32_t nranks,
                       int32_t band_rows, uint8_t* rgb_out_rank0);
 
+/* Glow post-process on the emission buffer: applyGlow() of the reference's CPU path (src/main.cpp:163-229 over
+ * downsample :32, gaussianBlur :97 and upscale :77), the step between the recomposed frame and writePPM
+ * (src/main.cpp:402-406).  rgb: height*width `pixel` bytes, modified in place; emission: height*width emissionPixel
+ * (4 floats), as rt_render_rows wrote them, read only (the reference frees its copy).  Host or device pointers.
+ * *levels_out (nullable): pyramid levels applied.  The CPU form is the specification -- a two-dimensional gaussian of
+ * (2 size + 1)^2 clamped taps, sigma 1000, size 8 doubling per level -- not the CUDA file's separable sigma-20 filter.
+ * RT_ERR_UNSUPPORTED (levels before it are applied): a level whose sizes times its factor are not the frame's -- the
+ * reference indexes the upscaled level with the frame's row length there and reads out of bounds (src/main.cpp:191-198
+ * over :77-95) -- i.e. width and height must be divisible by 2^levels; or a window above 257 x 257 (a fifth level). */
+int rt_apply_glow(rt_ctx* ctx, uint8_t* rgb, const float* emission, int32_t width, int32_t height, int32_t* levels_out);
+
 /* Tile streaming: replaces the producer side of the reference's Redis tile list (src/main.cpp:283-326 pushing through
  * Redis::SendImage, src/redis.h:27-36).  The frame is rendered in chunks of whole tile rows; after each chunk every
  * tile of it is handed to `sink` as the two records the reference pushes per tile, in this order:

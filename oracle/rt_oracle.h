@@ -56,6 +56,13 @@ int ro_render_strided(const ro_scene* scene, const ro_camera* cam, int W, int H,
 int ro_probe_max_depth(const ro_scene* scene, const ro_camera* cam, int W, int H, int maxdepth,
                        long seed_base, unsigned char* flags);
 
+/* Glow post-process (src/main.cpp:32-229, rt_glow.c: PARITY UNPINNED, see its header).  image: width*height `pixel`
+ * (3 bytes), modified in place; emission: width*height emissionPixel (4 floats), read only.  Returns the number of
+ * pyramid levels applied, -1 if a level's sizes do not divide the frame's (the reference reads out of bounds there). */
+int ro_apply_glow(unsigned char* image, const float* emission, int width, int height);
+/* the blur's normalised weights (src/main.cpp:101-123), kernel[(x + size) * (2 size + 1) + (y + size)] */
+void ro_glow_kernel(float sigma, int size, float* kernel);
+
 /* glibc srand()/rand() TYPE_3 restatement (rand.h:7,9). state: 31 words + 2 indices. */
 typedef struct { unsigned int r[31]; int f, b; } ro_rng;
 void ro_srand(ro_rng* g, unsigned int seed);

@@ -72,6 +72,8 @@ struct rt_ctx {
     void* d_classes = nullptr; size_t classes_bytes = 0;
     void* d_tiles = nullptr; size_t tiles_bytes = 0;   // rt_render_tiles: chunk rows + tile records
     void* d_gather = nullptr; size_t gather_bytes = 0; // rt_render_gather: band block | gather buffer | frame
+    void* d_glow = nullptr; size_t glow_bytes = 0;     // rt_apply_glow: level buffers | weights | staging
+    std::vector<float> glow_kernels[8];                // ... the blur's weights per pyramid level (host)
     void* d_heavy = nullptr; size_t heavy_bytes = 0;   // sample-parallel pixels: count | records | generator states
     size_t heavy_pool_bytes = 0;                       // ... its stream pool (sized from the pixel list, rt_render_rows)
     bool any_bounce = false;             // some material has reflection > 0 or refraction > 0
@@ -293,6 +295,7 @@ void rt_destroy(rt_ctx* ctx)
     if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->d_gather) (void)hipFree(ctx->d_gather);
+    if (ctx->d_glow) (void)hipFree(ctx->d_glow);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -903,6 +906,92 @@ int rt_render_gather(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* para
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return RT_OK;
+}
+
+// applyGlow (src/main.cpp:163-229) on the GPU: rt_glow.hip has the kernels.  The loop over pyramid levels runs here, as
+// in the reference; each level's largest strength comes back to decide whether another level follows (src/main.cpp:173).
+int rt_apply_glow(rt_ctx* ctx, uint8_t* rgb, const float* emission, int32_t width, int32_t height, int32_t* levels_out)
+{
+    if (levels_out) *levels_out = 0;
+    if (!ctx || !rgb || !emission || width <= 0 || height <= 0) return RT_ERR_INVALID_ARG;
+    if ((int64_t)width * height > (int64_t)1 << 30) return RT_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    const size_t npix = (size_t)width * height;
+    const bool rgb_dev = is_device_pointer(rgb), em_dev = is_device_pointer(emission);
+    // two level buffers (a level is at most a quarter of the frame; the first input is the frame's emission itself) |
+    // the blur's weights | the frame and its emission when they come from the host | the level's largest strength
+    const size_t level_bytes = ((npix / 4 + 1) * 16 + 255) & ~(size_t)255;
+    const size_t max_kernel = 257 * 257;                        // weights are uploaded per level; larger windows: see below
+    const size_t kernel_bytes = (max_kernel * 4 + 255) & ~(size_t)255;
+    size_t need = 2 * level_bytes + kernel_bytes + 256;
+    const size_t rgb_at = need; if (!rgb_dev) need += (npix * 3 + 255) & ~(size_t)255;
+    const size_t em_at = need;  if (!em_dev) need += npix * 16;
+    int rc = grow(ctx, &ctx->d_glow, &ctx->glow_bytes, need);
+    if (rc) return rc;
+    unsigned char* base = (unsigned char*)ctx->d_glow;
+    void* level[2] = { base, base + level_bytes };
+    float* d_kernel = (float*)(base + 2 * level_bytes);
+    unsigned int* d_max = (unsigned int*)(base + 2 * level_bytes + kernel_bytes);
+    unsigned char* d_rgb = rgb_dev ? rgb : base + rgb_at;
+    const void* d_em = em_dev ? (const void*)emission : (const void*)(base + em_at);
+    if (!rgb_dev) HIP_TRY(ctx, hipMemcpyAsync(d_rgb, rgb, npix * 3, hipMemcpyHostToDevice, ctx->stream));
+    if (!em_dev) HIP_TRY(ctx, hipMemcpyAsync((void*)d_em, emission, npix * 16, hipMemcpyHostToDevice, ctx->stream));
+
+    float max = 1.0f;
+    const int downScaleFactor = 2;
+    int upScaleFactor = downScaleFactor;
+    const int kernelSigma = (int)1000.0f;                       // `int kernelSigma = 1000.0f` (src/main.cpp:168)
+    int kernelSize = 8;
+    int w = width, h = height, levels = 0;
+    const void* src = d_em;
+    int status = RT_OK;
+    while (max >= 1 && w > 0 && h > 0) {
+        const int dW = w / downScaleFactor, dH = h / downScaleFactor;
+        // the reference reads upscaled[x + y*startW] from rows that are dW*upScaleFactor long: out of bounds unless equal
+        if (dW * upScaleFactor != width || dH * upScaleFactor != height) { status = RT_ERR_UNSUPPORTED; break; }
+        const size_t n = (size_t)(2 * kernelSize + 1);
+        if (n * n > max_kernel) { status = RT_ERR_UNSUPPORTED; break; }                  // (a 5th level of a frame > 4096 wide)
+        // the blur's weights (src/main.cpp:101-123): exp() in double, sums in float, in the reference's order
+        std::vector<float>& kernel = ctx->glow_kernels[levels < 8 ? levels : 7];       // kept: the same for every frame
+        if (kernel.size() != n * n) {
+            kernel.assign(n * n, 0.0f);
+            const float sigma = (float)kernelSigma;
+            float sum = 0.0f;
+            for (int y = -kernelSize; y <= kernelSize; ++y)
+                for (int x = -kernelSize; x <= kernelSize; ++x) {
+                    const float value = (float)std::exp((double)(-(x * x + y * y) / (2 * sigma * sigma)));
+                    kernel[(size_t)(x + kernelSize) * n + (size_t)(y + kernelSize)] = value;
+                    sum += value;
+                }
+            sum = 1.0f / sum;
+            for (size_t y = 0; y < n; ++y)
+                for (size_t x = 0; x < n; ++x) kernel[x * n + y] *= sum;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(d_kernel, kernel.data(), n * n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(d_max, 0, 4, ctx->stream));
+        // down: level[0], blurred: level[1].  From the second level on the source is the previous level's blurred image in
+        // level[1]: the downsample has read it before the blur (next on the stream) writes there again
+        void* down = level[0];
+        void* blurred = level[1];
+        HIP_TRY(ctx, rt_launch_glow_downsample(src, w, down, dW, dH, ctx->stream));
+        HIP_TRY(ctx, rt_launch_glow_blur(down, blurred, dW, dH, kernelSize, d_kernel, ctx->stream));
+        HIP_TRY(ctx, rt_launch_glow_add(d_rgb, blurred, dW, upScaleFactor, width, height, ctx->stream));
+        HIP_TRY(ctx, rt_launch_glow_filter(blurred, dW * dH, d_max, ctx->stream));
+        unsigned int bits = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&bits, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));        // (also: `kernel` may be overwritten)
+        std::memcpy(&max, &bits, 4);
+        w = dW; h = dH;
+        src = blurred;
+        upScaleFactor *= 2;
+        kernelSize *= 2;
+        ++levels;
+    }
+    if (!rgb_dev) HIP_TRY(ctx, hipMemcpyAsync(rgb, d_rgb, npix * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (levels_out) *levels_out = levels;
+    return status;
 }
 
 int rt_debug_rand(rt_ctx* ctx, const uint32_t* seeds, int32_t n_seeds, int32_t n_draws, int32_t* out)

@@ -4,7 +4,7 @@
 // / `new HittablesList` / `new DirectionalLight` / `new LightsList` calls, or an rtscene file.
 //
 //   rt_render [--scene file] [--w 1024 --h 512 --samples 5 --depth 10 --seed-base 0] [--out output.ppm]
-//             [--emission out.f32] [--probe] [--speedup] [--tiles 16 [--chunk-rows 128]]
+//             [--emission out.f32] [--glow] [--probe] [--speedup] [--tiles 16 [--chunk-rows 128]]
 //             [--frames 8 [--in-flight 4]]      frame k is seeded seed-base + 1000 k and written to <out>.<k>.ppm
 //             [--ranks N]                       one process per GPU (ranks 1..N-1 forked before anything touches a GPU), cyclic
 //                                               16-row bands, RCCL gather to rank 0 (GPU r = --device + r)
@@ -27,7 +27,7 @@ int main(int argc, char** argv)
 {
     RenderSettings st;
     const char* scenePath = nullptr; const char* out = "output.ppm"; const char* outEm = nullptr;
-    bool probe = false, speedup = false;
+    bool probe = false, speedup = false, glow = false;
     int tiles = 0, chunkRows = 0, frames = 0, inFlight = 4, ranks = 0;
     for (int i = 1; i < argc; ++i) {
         auto is = [&](const char* k) { return !std::strcmp(argv[i], k) && i + 1 < argc; };
@@ -47,6 +47,7 @@ int main(int argc, char** argv)
         else if (is("--ranks"))     ranks = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--probe"))   probe = true;
         else if (!std::strcmp(argv[i], "--speedup")) speedup = true;
+        else if (!std::strcmp(argv[i], "--glow"))    glow = true;
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
 
@@ -164,11 +165,17 @@ int main(int argc, char** argv)
         }
     } else {
         std::vector<pixel> image((size_t)st.width * st.height);
-        std::vector<emissionPixel> emission(outEm ? (size_t)st.width * st.height : 0);
+        std::vector<emissionPixel> emission((outEm || glow) ? (size_t)st.width * st.height : 0);
         double ms = 0.0;
         std::printf("Running Raytracing on MI355X...\n");
         int status = RenderImage(camera, world, lights, materials, materialsCount, st, image.data(),
-                                 outEm ? emission.data() : nullptr, &ms);
+                                 (outEm || glow) ? emission.data() : nullptr, &ms);
+        if (status == RT_OK && glow) {                                                   // src/main.cpp:400-404
+            std::printf("Running glow...\n");
+            int levels = 0;
+            status = ApplyGlow(image.data(), emission.data(), st.width, st.height, st.device, &levels);
+            if (status == RT_OK) std::printf("Glow: %d levels\n", levels);
+        }
         if (status != RT_OK) { std::fprintf(stderr, "RenderImage failed: %s\n", rt_strerror(status)); rc = 1; }
         else {
             std::printf("Ended in: %lf ms\n", ms);

@@ -117,6 +117,21 @@ inline int RenderImage(Camera& camera, Hittable* world, Light* lights, Material*
     return rc;
 }
 
+// applyGlow(image, emission, width, height) of the reference (src/main.cpp:163-229), on the GPU: image is modified in
+// place; unlike the reference's, `emission` is not freed.  Returns RT_OK or an rt_status (RT_ERR_UNSUPPORTED when a
+// pyramid level's sizes do not divide the frame's, where the reference reads out of bounds).
+inline int ApplyGlow(pixel* image, const emissionPixel* emission, int width, int height, int device = 0, int* levels = nullptr)
+{
+    rt_ctx* ctx = nullptr;
+    int rc = rt_create(&ctx, device);
+    if (rc != RT_OK) return rc;
+    int32_t n = 0;
+    rc = rt_apply_glow(ctx, reinterpret_cast<uint8_t*>(image), reinterpret_cast<const float*>(emission), width, height, &n);
+    if (levels) *levels = n;
+    rt_destroy(ctx);
+    return rc;
+}
+
 // One frame over `nranks` processes, one per GPU (this process is `rank`, on GPU settings.device): every rank renders
 // its cyclic 16-row bands, RCCL carries them to rank 0, which leaves the frame in image[width*height] -- the reference's
 // worker threads, Redis list and recompose loop (src/main.cpp:268-395) across GPUs.  commId: RT_COMM_ID_BYTES made by

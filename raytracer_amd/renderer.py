@@ -171,6 +171,13 @@ class Renderer:
         self._check(self._lib.rt_gather_rows(self._h, ctypes.c_void_p(comm) if comm else None, rank, nranks, _ptr(block), _ptr(gathered),
                                              _ptr(frame_out), width, height, bytes_per_pixel, band_rows, rows_per_rank), "rt_gather_rows")
 
+    def apply_glow(self, rgb, emission, width, height):
+        """rt_apply_glow: the reference's applyGlow() (src/main.cpp:163-229) on rgb [H, W, 3] uint8 in place, from emission
+        [H, W, 4] float32 (numpy = host, torch cuda tensors = device).  -> pyramid levels applied"""
+        levels = ctypes.c_int32(0)
+        self._check(self._lib.rt_apply_glow(self._h, _ptr(rgb), _ptr(emission), width, height, ctypes.byref(levels)), "rt_apply_glow")
+        return int(levels.value)
+
     @property
     def last_kernel_ms(self):
         return float(self._lib.rt_last_kernel_ms(self._h))

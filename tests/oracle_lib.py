@@ -101,6 +101,18 @@ def render_strided(scene, W, H, samples, maxdepth, seed_base=0, row0=0, rows=1, 
     return rgb, em, {"primary": cnt.primary, "closest": cnt.closest, "shadow": cnt.shadow, "tests": cnt.tests, "rand_draws": cnt.draws}
 
 
+def apply_glow(rgb, emission):
+    """oracle/rt_glow.c (PARITY UNPINNED restatement of src/main.cpp:32-229).  -> (rgb after glow, levels or -1)"""
+    l = lib()
+    l.ro_apply_glow.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    l.ro_apply_glow.restype = ctypes.c_int
+    H, W = rgb.shape[:2]
+    out = np.ascontiguousarray(rgb).copy()
+    em = np.ascontiguousarray(emission, dtype=np.float32)
+    levels = l.ro_apply_glow(out.ctypes.data, em.ctypes.data, W, H)
+    return out, levels
+
+
 def probe_max_depth(scene, W, H, maxdepth, seed_base=0):
     rs, keep = _pack(scene)
     cam = camera(scene, W, H)

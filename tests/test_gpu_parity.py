@@ -461,6 +461,41 @@ def test_gather_rows_over_rccl_single_rank(rt):
         rt.comm_destroy(comm)
 
 
+@pytest.mark.parametrize("name,W,H,samples", [("default4", 256, 128, 2), ("default4", 1024, 512, 1), ("glass_mirror", 192, 96, 2), ("default4", 48, 32, 1)])
+def test_glow_matches_the_cpu_restatement(rt, name, W, H, samples):
+    """f1: rt_apply_glow against oracle/rt_glow.c (applyGlow of src/main.cpp:163-229; the oracle is a restatement,
+    PARITY UNPINNED: the reference's main.cpp does not build here).  Bytes identical, same number of pyramid levels; host
+    and device buffers; the emission buffer is left as it was."""
+    import torch
+    sc = scenes.BUILTIN[name]()
+    rt.upload_scene(sc)
+    rgb, em, _ = rt.render(W, H, samples, 10, 3, emission=True)
+    want, levels = oracle_lib.apply_glow(rgb, em)
+    assert levels >= 1 and not np.array_equal(want, rgb)
+    got, em_in = rgb.copy(), em.copy()
+    assert rt.apply_glow(got, em_in, W, H) == levels
+    assert np.array_equal(got, want) and np.array_equal(em_in.view(np.uint32), em.view(np.uint32))
+    d_rgb, d_em = torch.from_numpy(rgb).cuda(), torch.from_numpy(em).cuda()
+    assert rt.apply_glow(d_rgb, d_em, W, H) == levels
+    assert np.array_equal(d_rgb.cpu().numpy(), want) and np.array_equal(d_em.cpu().numpy().view(np.uint32), em.view(np.uint32))
+
+
+def test_glow_levels_that_do_not_divide_the_frame_are_refused(rt):
+    """The reference indexes a level's upscaled image with the frame's row length (src/main.cpp:191-198): with sizes that
+    2^level does not divide it reads out of bounds.  Both sides stop there: the oracle returns -1, the library
+    RT_ERR_UNSUPPORTED, and the levels before it are applied."""
+    from raytracer_amd import _abi
+    sc = scenes.default4()
+    rt.upload_scene(sc)
+    W, H = 200, 100                                     # 100 / 8 is not whole: the third level is refused
+    rgb, em, _ = rt.render(W, H, 1, 10, 0, emission=True)
+    _, levels = oracle_lib.apply_glow(rgb, em)
+    assert levels == -1
+    with pytest.raises(ra.RtError) as e:
+        rt.apply_glow(rgb.copy(), em, W, H)
+    assert e.value.status == _abi.RT_ERR_UNSUPPORTED
+
+
 def test_probe_max_depth(rt, golden_dir):
     z = np.load(os.path.join(golden_dir, "probe_glass_mirror_128x64_d3_seed0.npz"))
     sc = scenes.Scene.from_text(bytes(z["scene"]).decode())

@@ -107,6 +107,21 @@ def test_cpp_driver_reads_reference_table_rows(golden_dir):
 
 
 @pytest.mark.gpu
+def test_cpp_driver_glow_matches_the_cpu_restatement(golden_dir):
+    """--glow: RenderImage() then ApplyGlow() (src/main.cpp:400-406 order), against oracle/rt_glow.c on the golden frame."""
+    import oracle_lib
+    z = np.load(os.path.join(golden_dir, "default4_256x128_s5_d10_seed1000.npz"))
+    want, levels = oracle_lib.apply_glow(z["rgb"], z["emission"])
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.ppm")
+        r = subprocess.run([EXE, "--w", "256", "--h", "128", "--samples", "5", "--depth", "10", "--seed-base", "1000",
+                            "--out", out, "--glow"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "Glow: %d levels" % levels in r.stdout
+        assert np.array_equal(_read_ppm(out), want)
+
+
+@pytest.mark.gpu
 def test_cpp_driver_scene_file_and_probe(golden_dir):
     z = np.load(os.path.join(golden_dir, "cube_128x64_s4_d10_seed0.npz"))
     with tempfile.TemporaryDirectory() as td:
