@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>      // types and prototypes only: the library is bound with dlopen (see rccl() below)
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -55,6 +56,7 @@ struct rt_ctx {
     float4* d_prim = nullptr;                    // camera-relative sphere terms, refreshed when the camera moves
     const unsigned int* d_order = nullptr;       // hittable indices sorted by type (cooperative scans)
     const unsigned int* d_slot_of = nullptr;     // the inverse: place of every hittable in that order
+    const float* d_clusters = nullptr; int n_clusters = 0;     // boxes of the rounds of 64 (centre, half extents, flag)
     std::vector<float> h_centres_r2;             // host copy of (centre, r^2) per hittable
     std::vector<float> h_prim;                   // staging for d_prim, sized by rt_upload_scene (no allocation per frame)
     float prim_cam[3] = { 0, 0, 0 }; bool prim_valid = false;
@@ -186,6 +188,7 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
     a.prim = ctx->d_prim;
     a.order = ctx->d_order;
     a.slot_of = ctx->d_slot_of;
+    a.clusters = ctx->d_clusters; a.n_clusters = ctx->n_clusters;
 }
 
 // Primary rays all start at the camera: origin - centre and dot(origin, origin) - r*r (sphere.h:15,19) are per-sphere
@@ -339,8 +342,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     }
 
     const int nh = s->n_hittables, nl = s->n_lights, nm = s->n_materials;
-    // hrec | lights | mats (padded to 4 floats) | prim (filled per camera) | type-sorted order of the hittables | its inverse
-    std::vector<float> img((size_t)nh * 8 + (size_t)nl * 4 + (size_t)nm * 10 + 4 + (size_t)nh * 4 + 2 * (size_t)nh, 0.0f);
+    // hrec | lights | mats (padded to 4 floats) | prim (filled per camera) | sorted order of the hittables | its inverse |
+    // the clusters' boxes, 8 floats each
+    const size_t nclusters = ((size_t)nh + 63) / 64;
+    std::vector<float> img((size_t)nh * 8 + (size_t)nl * 4 + (size_t)nm * 10 + 4 + (size_t)nh * 4 + 2 * (size_t)nh + 8 * nclusters, 0.0f);
     float* hrec = img.data();
     float* lights = hrec + (size_t)nh * 8;
     float* mats = lights + (size_t)nl * 4;
@@ -384,20 +389,98 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
         std::memcpy(&r[3], &type, 4);
     }
     if (nm > 0) std::memcpy(mats, s->materials, sizeof(float) * 10 * (size_t)nm);
-    // cooperative scans hand hittables to lanes in this order: same type side by side, so the 64 tests of a round
-    // mostly take the same branch (the winner is picked by index, so the order of testing does not matter)
+    // Cooperative scans hand hittables to lanes in this order: same type side by side, so the 64 tests of a round mostly
+    // take the same branch, and within a type in tiles, so the 64 hittables of a round -- a *cluster* -- sit together
+    // in space (the winner is picked by index, so the order of testing does not matter).  Per cluster an axis-aligned
+    // box (centre, half extents): a query whose ray certainly misses it skips the round (rt_device.hpp cluster_mask has
+    // the argument).  Planes and hittables with non-finite parameters make their cluster's box infinite: always
+    // visited.  Hittables much larger than the rest (a ground sphere) go to the end of their type, so that they spoil
+    // one cluster's box and not the tiling.
     const size_t prim_at = (size_t)nh * 8 + (size_t)nl * 4 + (((size_t)nm * 10 + 3) & ~(size_t)3);
+    const size_t clusters_at = prim_at + (size_t)nh * 6;
     {
+        // every hittable's box: spheres centre -/+ |radius| (sphere.h:19 squares the radius), cubes the two corners of
+        // cube.h:16-17 either way round (cube.h:19-20 sorts the slabs' ends)
+        std::vector<double> blo((size_t)nh * 3), bhi((size_t)nh * 3), ext((size_t)nh);
+        for (int i = 0; i < nh; ++i) {
+            const float* r = hrec + 8 * (size_t)i;
+            const int type = s->h_type[i];
+            double* l = &blo[(size_t)i * 3]; double* h = &bhi[(size_t)i * 3];
+            bool bounded = type == RT_SPHERE || type == RT_CUBE;
+            for (int k = 0; k < 3 && bounded; ++k) {
+                if (type == RT_SPHERE) { const double rad = std::fabs((double)s->h_radius[i]); l[k] = (double)r[k] - rad; h[k] = (double)r[k] + rad; }
+                else { const double p = r[k], q = r[4 + k]; l[k] = p < q ? p : q; h[k] = p < q ? q : p; }
+                bounded = std::isfinite(l[k]) && std::isfinite(h[k]);
+            }
+            double d2 = 0.0;
+            for (int k = 0; k < 3 && bounded; ++k) d2 += (h[k] - l[k]) * (h[k] - l[k]);
+            ext[(size_t)i] = bounded ? std::sqrt(d2) : INFINITY;
+        }
+        std::vector<double> sizes;
+        for (int i = 0; i < nh; ++i) if (std::isfinite(ext[(size_t)i])) sizes.push_back(ext[(size_t)i]);
+        double big = INFINITY;
+        if (!sizes.empty()) { std::nth_element(sizes.begin(), sizes.begin() + (long)(sizes.size() / 2), sizes.end()); big = 8.0 * sizes[sizes.size() / 2]; }
+        auto centre = [&](uint32_t i, int k) { return 0.5 * (blo[(size_t)i * 3 + k] + bhi[(size_t)i * 3 + k]); };
+        // tiles: order[from, to) is cut at the round boundary (a multiple of 64) nearest its middle, across the axis
+        // along which its centres spread most, until every piece lies within one round
         std::vector<uint32_t> order;
         order.reserve((size_t)nh);
-        for (int type = RT_SPHERE; type <= RT_CUBE; ++type)
-            for (int i = 0; i < nh; ++i)
-                if (s->h_type[i] == type) order.push_back((uint32_t)i);
+        struct Range { size_t from, to; };
+        std::vector<Range> todo;
+        auto tile = [&](size_t from0, size_t to0) {
+            todo.push_back({ from0, to0 });
+            while (!todo.empty()) {
+                const Range g = todo.back(); todo.pop_back();
+                if (g.to <= g.from || g.from / 64 == (g.to - 1) / 64) continue;
+                double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+                for (size_t j = g.from; j < g.to; ++j)
+                    for (int k = 0; k < 3; ++k) { const double c = centre(order[j], k); lo[k] = c < lo[k] ? c : lo[k]; hi[k] = c > hi[k] ? c : hi[k]; }
+                int axis = 0;
+                for (int k = 1; k < 3; ++k) if (hi[k] - lo[k] > hi[axis] - lo[axis]) axis = k;
+                std::stable_sort(order.begin() + (long)g.from, order.begin() + (long)g.to,
+                                 [&](uint32_t x, uint32_t y) { return centre(x, axis) < centre(y, axis); });
+                const size_t first = g.from / 64 + 1, last = (g.to - 1) / 64;            // boundaries first*64 .. last*64 lie inside
+                const size_t mid = 64 * (first + (last - first) / 2);
+                todo.push_back({ g.from, mid });
+                todo.push_back({ mid, g.to });
+            }
+        };
+        for (int type = RT_SPHERE; type <= RT_CUBE; ++type) {
+            const size_t from = order.size();
+            for (int i = 0; i < nh; ++i) if (s->h_type[i] == type && ext[(size_t)i] <= big) order.push_back((uint32_t)i);
+            tile(from, order.size());
+            for (int i = 0; i < nh; ++i) if (s->h_type[i] == type && std::isfinite(ext[(size_t)i]) && !(ext[(size_t)i] <= big)) order.push_back((uint32_t)i);
+            for (int i = 0; i < nh; ++i) if (s->h_type[i] == type && !std::isfinite(ext[(size_t)i])) order.push_back((uint32_t)i);
+        }
         if (nh > 0) std::memcpy(&img[prim_at + (size_t)nh * 4], order.data(), sizeof(uint32_t) * (size_t)nh);
         // ... and slot_of[hittable] = its place in that order (the sequential fallback walks the scene in scene order)
         std::vector<uint32_t> slot_of((size_t)nh);
         for (int j = 0; j < nh; ++j) slot_of[order[(size_t)j]] = (uint32_t)j;
         if (nh > 0) std::memcpy(&img[prim_at + (size_t)nh * 5], slot_of.data(), sizeof(uint32_t) * (size_t)nh);
+        // the clusters' boxes in float, rounded outwards: (centre.xyz, 1 if a cube is among the members: cluster_mask
+        // is more careful with those), (half.xyz, 0)
+        float* cl = nclusters > 0 ? &img[clusters_at] : nullptr;
+        for (size_t k = 0; k < nclusters; ++k) {
+            const size_t from = 64 * k, to = from + 64 < (size_t)nh ? from + 64 : (size_t)nh;
+            double l[3] = { 1e300, 1e300, 1e300 }, h[3] = { -1e300, -1e300, -1e300 };
+            bool open = false, cubes = false;
+            for (size_t j = from; j < to; ++j) {
+                const uint32_t i = order[j];
+                if (!std::isfinite(ext[i])) { open = true; continue; }
+                if (s->h_type[i] != RT_SPHERE) cubes = true;
+                for (int d = 0; d < 3; ++d) { l[d] = blo[(size_t)i * 3 + d] < l[d] ? blo[(size_t)i * 3 + d] : l[d]; h[d] = bhi[(size_t)i * 3 + d] > h[d] ? bhi[(size_t)i * 3 + d] : h[d]; }
+            }
+            float* c = cl + 8 * k;
+            for (int d = 0; d < 3; ++d) {
+                const float cf = open ? 0.0f : (float)(0.5 * (l[d] + h[d]));
+                const double need = open ? (double)INFINITY : std::fmax(h[d] - (double)cf, (double)cf - l[d]);   // covers [l, h] around cf
+                float hf = (float)need;
+                if ((double)hf < need) hf = std::nextafterf(hf, INFINITY);
+                c[d] = cf; c[4 + d] = hf;
+                if (!std::isfinite(cf) || !std::isfinite(hf)) { c[d] = 0.0f; c[4 + d] = INFINITY; }
+            }
+            c[3] = cubes ? 1.0f : 0.0f;
+        }
     }
 
     if (rt_launch_lds_bytes(nh, nl, nm) > 160 * 1024) return RT_ERR_UNSUPPORTED;
@@ -419,6 +502,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
     ctx->d_prim = (float4*)((float*)ctx->d_scene + prim_at);
     ctx->d_order = (const unsigned int*)((const float*)ctx->d_scene + prim_at + (size_t)nh * 4);
     ctx->d_slot_of = ctx->d_order + nh;
+    ctx->d_clusters = (const float*)ctx->d_scene + clusters_at;
+    ctx->n_clusters = (int)nclusters;
     ctx->h_centres_r2.resize((size_t)nh * 4);
     ctx->h_prim.assign((size_t)nh * 4, 0.0f);
     for (int i = 0; i < nh; ++i) std::memcpy(&ctx->h_centres_r2[4 * (size_t)i], hrec + 8 * (size_t)i, 16);

@@ -58,6 +58,8 @@ struct SceneLds {
     // null when the order is the scene's own (sphere-only scenes, every other kernel).
     const unsigned short* orig;
     const unsigned int* slot_of;
+    // coop_kernel: boxes (LDS, 8 floats each) of the rounds of 64 slots, for cluster_mask(); 0: none
+    const float* clusters; int n_clusters;
     // coop_kernel: per-wave candidate lists for the pixel's primary rays and their shadow rays (LDS, ascending indices);
     // a negative count means there is no list
     const unsigned short* cl_prim; int cl_nprim;
@@ -441,18 +443,102 @@ __device__ __forceinline__ int closest_hit_seq(const SceneLds& sc, v3 ro, v3 rd,
 template <bool HAS_NONSPHERE, bool COUNT, bool LIMITED, bool UNIFORM = true>
 __device__ __forceinline__ bool occluder_hit(float4 r0, float4 r1, v3 ro, v3 rd, float fa, v3 inv, float limit);
 
+// Minimum / maximum of a value over the 64 lanes, the same in every lane afterwards (no NaNs among the inputs): an
+// xor butterfly inside each row of 16 lanes by DPP (quad_perm [1,0,3,2], [2,3,0,1], row_ror 4 and 8 -- no LDS
+// traffic, unlike __shfl_xor's ds_bpermute), then the four rows' results by readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v)
+{
+    const int x = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_extreme(float v)
+{
+    auto pick = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+    v = pick(v, dpp_move<0xB1>(v));
+    v = pick(v, dpp_move<0x4E>(v));
+    v = pick(v, dpp_move<0x124>(v));
+    v = pick(v, dpp_move<0x128>(v));
+    const int x = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+    return pick(pick(r0, r1), pick(r2, r3));
+}
+
+// Which rounds of a cooperative scan can hold a hit at all.  The staged order puts hittables that are close in space
+// into the same round of 64 (rt_abi.cpp rt_upload_scene), and every round has an axis-aligned box around its members.
+// A round is skipped when intersect() *certainly* returns false for every member -- skipping a test that returns false
+// changes nothing (hittablesList.h:25-26 `continue`, :46) -- which is the case when the ray (t >= 0) misses the box
+// grown by a margin m on every side, m = D / 128, D = the distance from the ray's origin to the box's farthest corner
+// (D bounds every member's |ro - centre|, radius and |corner - ro|).  Then for every member either (a) the ray's line
+// stays >= m away from it, or (b) the line meets the member grown by m only over an interval that ends before t = 0.
+// Why the margin is enough (u = 2^-24):
+//   sphere.h:15-33, o = ro - centre, p = the centre's distance from the line, s = o.d / |d|.  The float discriminant
+//     b b - 4 a c is within 100 u D^2 d.d of 4 d.d (r^2 - p^2), b within 8 u D |d| of 2 s |d|, c within 7 u D^2 of
+//     p^2 + s^2 - r^2.  If p >= r + m / 2: 4 d.d (p^2 - r^2) >= d.d m^2 = 6e-5 D^2 d.d, ten times the error, so
+//     `discriminant < 0`; that covers (a).  Otherwise (b) says s > sqrt((r + m)^2 - p^2) > 0.86 m, so b > D |d| / 75 is
+//     positive, c >= 2 r m + m^2 >= 6e-5 D^2 is positive and 4 a c / b^2 >= 6e-5 >> u: the discriminant is negative or
+//     sqrtd < b strictly, both roots negative.
+//   cube.h:15-26.  Every t = (corner - origin) * (1 / d) is within 3 u |t| of its value.  (a): at the point P where
+//     the line leaves the first slab (tMax) it is >= m from the cube, so outside another slab k by >= m / sqrt 2,
+//     which it enters at tMax + g, g >= m / (sqrt 2 |d_k|); |t_enter_k| <= D / |d_k| and |tMax| <= |t_enter_k| + g, so
+//     the computed tMin - tMax >= g - 3 u (2 D / |d_k| + g) > 0.  (b): min_i (t_exit_i + m / |d_i|) < 0, so for that
+//     i the computed t_exit_i, and with it tMax, is negative (|t_exit_i| > m / |d_i|: far from rounding to -0).
+//     Both need 1 / d_i finite and the products neither NaN nor infinite (cube.h's comparisons come out `true` on
+//     those): rounds with a cube in them are only skipped for rays with every |d_i| > 1e-12.
+//   Overflow and underflow would break these bounds (a NaN discriminant *is* a hit, sphere.h:22,32): nothing is skipped
+//   unless d.d is within [1e-6, 1e6] and D within [1e-6, 1e12] (NaNs fail that too).
+//   Planes and hittables with non-finite parameters make their round's box infinite: always visited.
+// The miss is proved by a separating axis (the box's three, for the half-line; d x e_i, for the line), in float, with
+// the box (rounded outwards, rt_abi.cpp) grown by D / 100: every term of the comparisons is bounded by D |d_i|, the
+// float evaluation is off by less than 9 u of that, 1e-4 of the D |d_i| / 128 the argument needs -- the difference
+// between / 100 and / 128 is there for it.
+// All lanes of the wave hold the same ray; lane k decides round k (at most 64 rounds: RT_MAX_HITTABLES = 4096).
+__device__ __forceinline__ unsigned long long cluster_mask(const SceneLds& sc, v3 ro, v3 rd)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    bool visit = lane < sc.n_clusters;            // (n_clusters = ceil(n_hit / 64) wherever the cooperative scans run)
+    if (visit) {
+        const float4 c = ((const float4*)sc.clusters)[2 * lane], h = ((const float4*)sc.clusters)[2 * lane + 1];
+        const float ax = fabsf(rd.x), ay = fabsf(rd.y), az = fabsf(rd.z);
+        const float ox = c.x - ro.x, oy = c.y - ro.y, oz = c.z - ro.z;
+        const float fx = fabsf(ox) + h.x, fy = fabsf(oy) + h.y, fz = fabsf(oz) + h.z;
+        const float dd = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z, D2 = fx * fx + fy * fy + fz * fz;
+        bool usable = dd >= 1e-6f && dd <= 1e6f && D2 >= 1e-12f && D2 <= 1e24f;
+        if (c.w != 0.0f) usable = usable && ax > 1e-12f && ay > 1e-12f && az > 1e-12f;
+        if (usable) {
+            const float m = sqrtf(D2) * 0.01f;
+            const float Hx = h.x + m, Hy = h.y + m, Hz = h.z + m;
+            bool miss = (ox > Hx && rd.x <= 0.0f) || (ox < -Hx && rd.x >= 0.0f)
+                     || (oy > Hy && rd.y <= 0.0f) || (oy < -Hy && rd.y >= 0.0f)
+                     || (oz > Hz && rd.z <= 0.0f) || (oz < -Hz && rd.z >= 0.0f);
+            miss = miss || fabsf(oy * rd.z - oz * rd.y) > Hy * az + Hz * ay
+                        || fabsf(oz * rd.x - ox * rd.z) > Hx * az + Hz * ax
+                        || fabsf(ox * rd.y - oy * rd.x) > Hx * ay + Hy * ax;
+            visit = !miss;
+        }
+    }
+    return __ballot(visit);
+}
+
 template <bool HAS_NONSPHERE>
 __device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd, float& best)
 {
     const int lane = (int)(threadIdx.x & 63);
-    const bool sorted = HAS_NONSPHERE && sc.orig != nullptr;
+    const bool sorted = sc.orig != nullptr;
     float fa = 4.0f * dot(rd, rd);
     v3 inv = mk(0, 0, 0);
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     best = 3.402823466e+38f;
     int bi = -1;
     bool nan_seen = false;
-    for (int j = lane; j < sc.n_hit; j += 64) {
+    // the rounds that can hold a hit (all of them without clusters)
+    unsigned long long rounds = cluster_mask(sc, ro, rd);
+    while (rounds != 0ull) {
+        const int j = 64 * __builtin_ctzll(rounds) + lane;
+        rounds &= rounds - 1ull;
+        if (j >= sc.n_hit) continue;
         float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
         float t;
         if (hittable_hit<HAS_NONSPHERE, false>(r0, r1, ro, rd, fa, inv, t)) {
@@ -462,17 +548,25 @@ __device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd
         }
     }
     if (__ballot(nan_seen) != 0ull) return closest_hit_seq<HAS_NONSPHERE>(sc, ro, rd, best);
-    int bo = (sorted && bi >= 0) ? (int)sc.orig[bi] : bi;      // the winner's index in the scene
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        float ot = __shfl_xor(best, m);
-        int oo = __shfl_xor(bo, m);
-        int oi = sorted ? __shfl_xor(bi, m) : oo;
-        // no-hit lanes carry (FLT_MAX, -1): any hit is below FLT_MAX, two hits at the same distance go to the lower index
-        bool take = ot < best || (ot == best && oo >= 0 && (bo < 0 || oo < bo));
-        if (take) { best = ot; bo = oo; bi = oi; }
+    // The winner over the lanes: the smallest distance (no-hit lanes carry FLT_MAX, which no hit reaches); two hits at the
+    // same distance go to the lower index in the scene.
+    const float tmin = wave_extreme<false>(best);
+    unsigned long long cand = __ballot(bi >= 0 && best == tmin);
+    if (cand == 0ull) { best = 3.402823466e+38f; return -1; }
+    int wl = __builtin_ctzll(cand);
+    cand &= cand - 1ull;
+    if (cand != 0ull) {                                          // a tie between lanes (rare)
+        const int bo = sorted ? (int)sc.orig[bi >= 0 ? bi : 0] : bi;
+        int wo = __builtin_amdgcn_readlane(bo, wl);
+        while (cand != 0ull) {
+            const int l = __builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            const int o = __builtin_amdgcn_readlane(bo, l);
+            if (o < wo) { wo = o; wl = l; }
+        }
     }
-    return bi;
+    best = tmin;
+    return __builtin_amdgcn_readlane(bi, wl);
 }
 
 template <bool HAS_NONSPHERE, bool LIMITED>
@@ -483,8 +577,10 @@ __device__ __forceinline__ bool any_hit_coop(const SceneLds& sc, v3 ro, v3 rd, f
     v3 inv = mk(0, 0, 0);
     if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     // 64 hittables per round; the first round with an occluder ends the query (any order gives the same boolean)
-    for (int base = 0; base < sc.n_hit; base += 64) {
-        const int j = base + lane;
+    unsigned long long rounds = cluster_mask(sc, ro, rd);
+    while (rounds != 0ull) {
+        const int j = 64 * __builtin_ctzll(rounds) + lane;
+        rounds &= rounds - 1ull;
         bool o = false;
         if (j < sc.n_hit) {
             float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
@@ -543,7 +639,7 @@ __device__ __forceinline__ int closest_hit_seq(const SceneLds& sc, v3 ro, v3 rd,
     best = 3.402823466e+38f;
     int bi = -1;
     for (int k = 0; k < sc.n_hit; ++k) {
-        const int j = (HAS_NONSPHERE && sc.slot_of) ? (int)sc.slot_of[k] : k;
+        const int j = sc.slot_of ? (int)sc.slot_of[k] : k;
         float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
         float t;
         if (hittable_hit<HAS_NONSPHERE, false>(r0, r1, ro, rd, fa, inv, t) && !(t >= best)) { best = t; bi = j; }
@@ -655,18 +751,14 @@ __device__ __forceinline__ float light_intensity_coop(const SceneLds& sc, v3 pos
     }
     float intensity = 0.085f;
     for (int turn = 0; turn < sc.n_lights; ++turn) {
-        float best = my > intensity ? my : -1.0f;
-        int who = lane;
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            float ob = __shfl_xor(best, m);
-            int ow = __shfl_xor(who, m);
-            if (ob > best || (ob == best && ow < who)) { best = ob; who = ow; }
-        }
+        // the largest term left that could raise the intensity; among equals the first light
+        const float best = wave_extreme<true>(my > intensity ? my : -1.0f);
         if (!(best > intensity)) break;                      // no light left that could raise it
-        const v3 l = mk(__shfl(lx, who), __shfl(ly, who), __shfl(lz, who));
-        const int type = __shfl(ltype, who);
-        const float dist = __shfl(ldist, who);
+        const int who = __builtin_ctzll(__ballot(my == best));
+        auto from = [who](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), who)); };
+        const v3 l = mk(from(lx), from(ly), from(lz));
+        const int type = __builtin_amdgcn_readlane(ltype, who);
+        const float dist = from(ldist);
         const bool occluded = (type == L_DIR) ? any_hit_coop<HAS_NONSPHERE, false>(sc, position, l, 0.0f)
                                               : any_hit_coop<HAS_NONSPHERE, true>(sc, position, l, dist);
         if (!occluded) { intensity = best; break; }

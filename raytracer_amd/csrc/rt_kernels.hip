@@ -12,9 +12,11 @@
 //                     out rand() stream at guessed indices; resume_kernel finishes what it gives up on;
 //   coop_kernel    -- listed pixels of large scenes, one wave per pixel, the lanes share every scan of the scene;
 //   tile_pack / deinterleave / probe / debug kernels.
-#include "rt_device.hpp"
 #include "rt_launch.h"
+#include "rt_device.hpp"
 #include <type_traits>
+#include <cstdio>
+#include <cstdlib>
 
 namespace rt {
 
@@ -65,6 +67,21 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
     float4 stk_em[(MIXED && EMISSION) ? MAXSP : 1];
     float4 pend[MIXED ? 3 * MAXPEND : 1];
     int sp = 0, pp = 0;
+    // coop_kernel: the 64 lanes of the wave hold one path, so one copy of its frames is enough -- lane 0's; the others
+    // neither write theirs nor use what they read back
+    constexpr bool ONE_COPY = BATCH == RT_COOP;
+    const bool keeper = !ONE_COPY || (threadIdx.x & 63) == 0;
+    auto put = [&](float4* arr, int i, float4 v) { if (keeper) arr[i] = v; };
+    auto get = [&](const float4* arr, int i) -> float4 {
+        float4 v = arr[i];
+        if (ONE_COPY) {
+            v.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.x)));
+            v.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.y)));
+            v.z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.z)));
+            v.w = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.w)));
+        }
+        return v;
+    };
 
     float mult = 1.0f;
     int depth = 1;
@@ -122,13 +139,13 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
                         if (dot(d, hnorm) > 0) {
                             if (sp >= MAXSP || (MIXED && pp >= MAXPEND)) { *fault = 1; break; }
                             bool mixed = MIXED && m[5] > 0;
-                            stk[sp] = make_float4(color.x, color.y, color.z,
-                                                  __int_as_float(mat | (TAG_REFL << 8) | ((int)mixed << 9)));
+                            put(stk, sp, make_float4(color.x, color.y, color.z,
+                                                     __int_as_float(mat | (TAG_REFL << 8) | ((int)mixed << 9))));
                             if (MIXED && mixed) {
-                                if (EMISSION) stk_em[sp] = make_float4(emission.x, emission.y, emission.z, strength);
-                                pend[3 * pp + 0] = make_float4(hpos.x, hpos.y, hpos.z, mult);
-                                pend[3 * pp + 1] = make_float4(hnorm.x, hnorm.y, hnorm.z, __int_as_float(depth));
-                                pend[3 * pp + 2] = make_float4(inDir.x, inDir.y, inDir.z, 0.0f);
+                                if (EMISSION) put(stk_em, sp, make_float4(emission.x, emission.y, emission.z, strength));
+                                put(pend, 3 * pp + 0, make_float4(hpos.x, hpos.y, hpos.z, mult));
+                                put(pend, 3 * pp + 1, make_float4(hnorm.x, hnorm.y, hnorm.z, __int_as_float(depth)));
+                                put(pend, 3 * pp + 2, make_float4(inDir.x, inDir.y, inDir.z, 0.0f));
                                 ++pp;
                             }
                             ++sp;
@@ -163,9 +180,9 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
                     d = normalize(d + hemi * m[3]);
                     if (sp >= MAXSP) { *fault = 1; sp = 0; break; }
                     bool mixed = MIXED && reflection > 0;
-                    stk[sp] = make_float4(color.x, color.y, color.z,
-                                          __int_as_float(mat | (TAG_REFR << 8) | ((int)mixed << 9)));
-                    if (MIXED && EMISSION && mixed) stk_em[sp] = make_float4(emission.x, emission.y, emission.z, strength);
+                    put(stk, sp, make_float4(color.x, color.y, color.z,
+                                             __int_as_float(mat | (TAG_REFR << 8) | ((int)mixed << 9))));
+                    if (MIXED && EMISSION && mixed) put(stk_em, sp, make_float4(emission.x, emission.y, emission.z, strength));
                     ++sp;
                     ro = hpos + d * 0.01f; rd = d;                               // renderer.h:116
                     mult = mult * 0.9f;                                          // renderer.h:118 (same depth)
@@ -180,7 +197,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
                 // every remaining frame only adds its colour (renderer.h:83,119): fetch four frames per round trip,
                 // add them in the same order
                 while (sp >= 4) {
-                    float4 f0 = stk[sp - 1], f1 = stk[sp - 2], f2 = stk[sp - 3], f3 = stk[sp - 4];
+                    float4 f0 = get(stk, sp - 1), f1 = get(stk, sp - 2), f2 = get(stk, sp - 3), f3 = get(stk, sp - 4);
                     sp -= 4;
                     color = mk(f0.x, f0.y, f0.z) + color;
                     color = mk(f1.x, f1.y, f1.z) + color;
@@ -190,7 +207,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
                 if (sp == 0) break;
             }
             --sp;
-            float4 fr = stk[sp];
+            float4 fr = get(stk, sp);
             int meta = __float_as_int(fr.w);
             int pmat = meta & 255;
             int tag = (meta >> 8) & 1;
@@ -199,7 +216,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
             color = mk(fr.x, fr.y, fr.z) + color;                                // renderer.h:83,119
             if (EMISSION) {
                 v3 pem; float pst;
-                if (MIXED && mixed) { float4 e = stk_em[sp]; pem = mk(e.x, e.y, e.z); pst = e.w; }
+                if (MIXED && mixed) { float4 e = get(stk_em, sp); pem = mk(e.x, e.y, e.z); pst = e.w; }
                 else                { pem = mk(pm[6], pm[7], pm[8]); pst = pm[9]; }
                 if (strength > 0) {                                              // renderer.h:85-89,121-125
                     pem = normalize(pem * pst + emission * strength);
@@ -211,7 +228,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
             mat = pmat;
             if (MIXED && mixed && tag == TAG_REFL) {
                 --pp;
-                float4 p0 = pend[3 * pp + 0], p1 = pend[3 * pp + 1], p2 = pend[3 * pp + 2];
+                float4 p0 = get(pend, 3 * pp + 0), p1 = get(pend, 3 * pp + 1), p2 = get(pend, 3 * pp + 2);
                 hpos = mk(p0.x, p0.y, p0.z); mult = p0.w;
                 hnorm = mk(p1.x, p1.y, p1.z); depth = __float_as_int(p1.w);
                 inDir = mk(p2.x, p2.y, p2.z);
@@ -242,21 +259,21 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     sc.hrec = l_hrec; sc.lights = l_lights; sc.mats = l_mats;
     sc.n_hit = a.n_hit; sc.n_lights = a.n_lights;
     sc.khrec = (kptr4)a.hrec; sc.klights = (kptr4)a.lights; sc.kprim = (kptr4)a.prim;
-    sc.orig = nullptr; sc.slot_of = nullptr;
+    sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0;
     sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
     __syncthreads();
 }
 
-// coop_kernel's staging: the hittables sorted by type (a.order), so that lane l of a cooperative scan reads slot
-// base + l and the 64 tests of a round mostly take one branch; l_orig[slot] = index in the scene.  Sphere-only scenes
-// are in that order already.
-template <bool HAS_NONSPHERE>
+// coop_kernel's staging: the hittables in the order of a.order -- by type, so that lane l of a cooperative scan reads
+// slot base + l and the 64 tests of a round mostly take one branch, and within a type along a space-filling curve, so
+// that a round's hittables sit together in space and whole rounds can be skipped (rt_device.hpp cluster_mask) -- with
+// l_orig[slot] = index in the scene and the rounds' boxes behind them.
 __device__ __forceinline__ void stage_scene_sorted(const KernelArgs& a, float4* lds, SceneLds& sc, float*& lds_free)
 {
     stage_scene(a, lds, sc, lds_free);
-    if (!HAS_NONSPHERE) return;
     float4* l_hrec = lds;
     unsigned short* l_orig = (unsigned short*)lds_free;
+    float* l_clusters = lds_free + (((size_t)a.n_hit * 2 + 15) & ~(size_t)15) / 4;
     const int nthreads = (int)blockDim.x;
     __syncthreads();                                   // (stage_scene's copy is replaced: nobody reads it in between)
     for (int j = threadIdx.x; j < a.n_hit; j += nthreads) {
@@ -264,8 +281,10 @@ __device__ __forceinline__ void stage_scene_sorted(const KernelArgs& a, float4* 
         l_hrec[2 * j] = a.hrec[2 * i]; l_hrec[2 * j + 1] = a.hrec[2 * i + 1];
         l_orig[j] = (unsigned short)i;
     }
-    lds_free += (((size_t)a.n_hit * 2 + 15) & ~(size_t)15) / 4;
+    for (int j = threadIdx.x; j < 8 * a.n_clusters; j += nthreads) l_clusters[j] = a.clusters[j];
+    lds_free = l_clusters + 8 * a.n_clusters;
     sc.orig = l_orig; sc.slot_of = a.slot_of;
+    sc.clusters = l_clusters; sc.n_clusters = a.n_clusters;
     __syncthreads();
 }
 
@@ -839,16 +858,22 @@ __global__ __launch_bounds__(BLOCK, RT_LISTED_WAVES) void heavy_kernel(KernelArg
 // pixel's primary directions, the generator's words -- exists once per wave in LDS (every lane reads and writes the
 // same words with the same values), so a workgroup of COOP_WAVES waves needs little more than the staged scene and
 // two of them fit a CU next to a 2049-hittable scene.
-constexpr int COOP_WAVES = 8;
+#ifndef RT_COOP_WAVES
+#define RT_COOP_WAVES 12
+#endif
+#ifndef RT_COOP_MIN_WAVES
+#define RT_COOP_MIN_WAVES 6
+#endif
+constexpr int COOP_WAVES = RT_COOP_WAVES;
 constexpr int COOP_LIST = 64;     // entries of a wave's candidate list (more candidates: no list, every scan covers the scene)
 
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
-__global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
+__global__ __launch_bounds__(COOP_WAVES * 64, RT_COOP_MIN_WAVES) void coop_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
     SceneLds sc;
     float* lds_free;
-    stage_scene_sorted<HAS_NONSPHERE>(a, lds, sc, lds_free);
+    stage_scene_sorted(a, lds, sc, lds_free);
     __builtin_amdgcn_s_setprio(3);
 
     const int wave = (int)(threadIdx.x >> 6);
@@ -880,8 +905,13 @@ __global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
     primary_directions<COOP_WAVES>(a, dirs, x, y);
     int nprim = 0, noccl = 0;
     bool fits = true;
-    for (int base = 0; base < sc.n_hit && fits; base += 64) {
-        const int i = base + lane;
+    unsigned long long rounds = 0ull;                  // rounds that can hold a hit of one of the four directions
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k)
+        rounds |= cluster_mask(sc, origin, mk(dirs[(3 * k + 0) * COOP_WAVES], dirs[(3 * k + 1) * COOP_WAVES], dirs[(3 * k + 2) * COOP_WAVES]));
+    while (rounds != 0ull && fits) {
+        const int i = 64 * __builtin_ctzll(rounds) + lane;
+        rounds &= rounds - 1ull;
         bool any = false;
         if (i < sc.n_hit) {
             const float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
@@ -901,7 +931,7 @@ __global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
         else if (any) lp[nprim + __popcll(m & below)] = (unsigned short)i;           // ascending slots
         nprim += add;
     }
-    if (HAS_NONSPHERE && fits && nprim > 1) {
+    if (fits && nprim > 1) {
         // closest-hit queries walk this list with the sequential rule: it has to be in scene order, not slot order
         unsigned short slot = 0;
         int rank = 0;
@@ -929,8 +959,10 @@ __global__ __launch_bounds__(COOP_WAVES * 64) void coop_kernel(KernelArgs a)
                 const float fa = 4.0f * dot(l, l);
                 v3 inv = mk(0, 0, 0);
                 if (HAS_NONSPHERE) inv = mk(1.0f / l.x, 1.0f / l.y, 1.0f / l.z);
-                for (int base = 0; base < sc.n_hit && fits; base += 64) {
-                    const int i = base + lane;
+                unsigned long long lrounds = cluster_mask(sc, pos, l);
+                while (lrounds != 0ull && fits) {
+                    const int i = 64 * __builtin_ctzll(lrounds) + lane;
+                    lrounds &= lrounds - 1ull;
                     bool o = false;
                     if (i < sc.n_hit) {
                         const float4 r0 = sc.hrec[2 * i], r1 = sc.hrec[2 * i + 1];
@@ -1353,7 +1385,7 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.orig = nullptr; sc.slot_of = nullptr; sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
+    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0; sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
     v3 ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     float4 r0 = hrec[2 * index], r1 = hrec[2 * index + 1];
     float fa = 4.0f * dot(rd, rd);
@@ -1377,9 +1409,9 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 using namespace rt;
 
 // kernel variants by (emission buffer, reflect-and-refract material, planes or cubes).  RT_DEV_FAST (experiments only):
-// just the two that the bench workloads use, for a quick build.
+// just the three that the bench workloads use, for a quick build.
 #ifdef RT_DEV_FAST
-#define RT_ALL_VARIANTS(X) X(false, false, false) X(false, true, true)
+#define RT_ALL_VARIANTS(X) X(false, false, false) X(false, false, true) X(false, true, true)
 #else
 #define RT_ALL_VARIANTS(X) X(false, false, false) X(false, false, true) X(false, true, false) X(false, true, true) \
                            X(true, false, false)  X(true, false, true)  X(true, true, false)  X(true, true, true)
@@ -1517,6 +1549,10 @@ static hipError_t launch_rays(K k, const KernelArgs& a, size_t lds_bytes, hipStr
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
+    if (const char* dbg = getenv("RT_DEBUG_COOP")) {
+        fprintf(stderr, "[rt] coop launch: lds %zu B, %d workgroups of %d waves per CU by the occupancy query, %d CUs\n", lds_bytes, per_cu, COOP_WAVES, cus);
+        if (atoi(dbg) > 1) per_cu = atoi(dbg);
+    }
     const int resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
     if (blocks > resident) blocks = resident;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(RAYS_WAVES * 64), lds_bytes, stream, a);
@@ -1537,9 +1573,9 @@ hipError_t rt_launch_rays(const KernelArgs& a, const LaunchTraits& t, hipStream_
 
 static size_t coop_lds_bytes(int n_hit, int n_lights, int n_mat)
 {
-    // (+ the slot -> scene index table of stage_scene_sorted)
+    // (+ the slot -> scene index table and the clusters' boxes of stage_scene_sorted)
     size_t nm = (size_t)((10 * n_mat + 3) & ~3);
-    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (((size_t)n_hit * 2 + 15) & ~(size_t)15)
+    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (((size_t)n_hit * 2 + 15) & ~(size_t)15) + (size_t)((n_hit + 63) / 64) * 32
          + (size_t)(12 + 32) * COOP_WAVES * 4 + (size_t)COOP_WAVES * 2 * COOP_LIST * 2 + 16;
 }
 
@@ -1562,6 +1598,10 @@ static hipError_t launch_coop(K k, const KernelArgs& a, int blocks, size_t lds_b
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
+    if (const char* dbg = getenv("RT_DEBUG_COOP")) {
+        fprintf(stderr, "[rt] coop launch: lds %zu B, %d workgroups of %d waves per CU by the occupancy query, %d CUs\n", lds_bytes, per_cu, COOP_WAVES, cus);
+        if (atoi(dbg) > 1) per_cu = atoi(dbg);
+    }
     const int resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
     if (blocks > resident) blocks = resident;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(COOP_WAVES * 64), lds_bytes, stream, a);

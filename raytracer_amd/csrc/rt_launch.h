@@ -35,6 +35,8 @@ struct KernelArgs {
     const float4* prim;          // n_hit: per sphere (camera - centre, |camera - centre|^2 - r^2) for primary rays
     const unsigned int* order;   // n_hit: hittable indices sorted by type, the order coop_kernel stages them in
     const unsigned int* slot_of; // n_hit: the inverse (place of hittable i in `order`)
+    const float* clusters;       // ceil(n_hit / 64) x 8 floats (centre.xyz, has-cubes, half.xyz, 0): boxes of the rounds of 64 in `order`
+    int n_clusters;
     unsigned char* rgb;          // rows * width * 3 (probe: width * height flags)
     float4* emission;            // rows * width, or null
     unsigned long long* counters;// 5 words (closest, shadow, tests, draws, shaded), or null
