@@ -148,6 +148,7 @@ def cpu_baseline(scene, W, H, samples, depth, count_rays, budget_s=20.0):
 
 
 def main():
+    t_start = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -155,6 +156,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0, help="frames of one rank under way at once (default %d)" % DEFAULT_IN_FLIGHT)
     ap.add_argument("--workload", default="default4_4k_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--estimate-tally", action="store_true", help="tally every 32nd row and scale instead of the whole frame (large scenes: the exact tally takes most of a minute)")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed frame with the CPU oracle")
     ap.add_argument("--flags", type=int, default=0, help="extra rt_params.flags for A/B runs (4 = RT_FLAG_SINGLE_KERNEL, 8 = RT_FLAG_FORCE_SAMPLE_PARALLEL)")
     args = ap.parse_args()
@@ -256,6 +258,11 @@ def main():
     elapsed = time.perf_counter() - t0
     # untimed: the last frame of the timed region against the CPU oracle (the plain-C port, pinned to the reference by
     # tests/test_oracle_golden.py) on every vstep-th row -- the rows the cpu_baseline leg samples
+    def progress(what):              # (stderr: the one JSON line stays alone on stdout; a silent run reads as hung)
+        if rank == 0:
+            print("[bench] %s (%.0f s)" % (what, time.perf_counter() - t_start), file=sys.stderr, flush=True)
+
+    progress("timed region done: %d frame(s) in %.3f s" % (args.steps, elapsed))
     verified = None
     if rank == 0 and not args.no_verify:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -286,12 +293,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    progress("verification done" if verified is not None else "verification skipped")
     # exact tallies of this frame (untimed): the counting build issues every query the reference issues
     pc = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank)
     tally_note = "queries of the reference algorithm for this frame, tallied by the device's counting build (equal to the oracle's tallies: tests/test_gpu_parity.py, tests/test_gpu_fullsize.py)"
-    if len(scene.hittables) >= 256:
-        # the counting build is one lane per pixel: minutes for a large scene.  Tally every 32nd row of this rank's
-        # rows and scale -- an estimate, flagged as such.
+    if args.estimate_tally:
+        # the counting build is one lane per pixel over the whole scene: most of a minute for a 1080p frame of a
+        # 2049-hittable scene.  On request, tally every 32nd row of this rank's rows and scale -- an estimate, flagged
+        # as such.
         step = 32
         n = max(1, p.rows // step)
         ps = rt.params(W, H, samples, depth, seed, row0=pc.row0, rows=n, band_rows=1, band_stride=step * world)
@@ -300,6 +309,7 @@ def main():
         tally_note = "estimate: reference-algorithm queries of every %d-th row, scaled to the frame" % step
     else:
         cnt = rt.render_rows(cam, pc, block, count=True)
+    progress("tally done")
     keys = ("primary", "closest", "shadow", "tests", "rand_draws", "shaded")
     tv = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device=rdev)
     local_flops = algorithmic_flops(cnt, scene, W * p.rows, samples)
@@ -369,6 +379,7 @@ def main():
                 n = (H + step - 1) // step
                 ps = rt.params(W, H, samples, depth, seed, row0=0, rows=n, band_rows=1, band_stride=step)
                 return rt.render_rows(cam, ps, block[:n], count=True)["closest"]
+            progress("timing the CPU baseline")
             line["cpu_baseline"] = cpu_baseline(scene, W, H, samples, depth, count_rays)
         print(json.dumps(line), flush=True)
         if verified is not None and not verified["identical"]:

@@ -494,31 +494,32 @@ __device__ __forceinline__ float wave_extreme(float v)
 // the box (rounded outwards, rt_abi.cpp) grown by D / 100: every term of the comparisons is bounded by D |d_i|, the
 // float evaluation is off by less than 9 u of that, 1e-4 of the D |d_i| / 128 the argument needs -- the difference
 // between / 100 and / 128 is there for it.
+__device__ __forceinline__ bool cluster_may_hit(float4 c, float4 h, v3 ro, v3 rd)
+{
+    const float ax = fabsf(rd.x), ay = fabsf(rd.y), az = fabsf(rd.z);
+    const float ox = c.x - ro.x, oy = c.y - ro.y, oz = c.z - ro.z;
+    const float fx = fabsf(ox) + h.x, fy = fabsf(oy) + h.y, fz = fabsf(oz) + h.z;
+    const float dd = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z, D2 = fx * fx + fy * fy + fz * fz;
+    bool usable = dd >= 1e-6f && dd <= 1e6f && D2 >= 1e-12f && D2 <= 1e24f;
+    if (c.w != 0.0f) usable = usable && ax > 1e-12f && ay > 1e-12f && az > 1e-12f;
+    if (!usable) return true;
+    const float m = sqrtf(D2) * 0.01f;
+    const float Hx = h.x + m, Hy = h.y + m, Hz = h.z + m;
+    bool miss = (ox > Hx && rd.x <= 0.0f) || (ox < -Hx && rd.x >= 0.0f)
+             || (oy > Hy && rd.y <= 0.0f) || (oy < -Hy && rd.y >= 0.0f)
+             || (oz > Hz && rd.z <= 0.0f) || (oz < -Hz && rd.z >= 0.0f);
+    miss = miss || fabsf(oy * rd.z - oz * rd.y) > Hy * az + Hz * ay
+                || fabsf(oz * rd.x - ox * rd.z) > Hx * az + Hz * ax
+                || fabsf(ox * rd.y - oy * rd.x) > Hx * ay + Hy * ax;
+    return !miss;
+}
+
 // All lanes of the wave hold the same ray; lane k decides round k (at most 64 rounds: RT_MAX_HITTABLES = 4096).
 __device__ __forceinline__ unsigned long long cluster_mask(const SceneLds& sc, v3 ro, v3 rd)
 {
     const int lane = (int)(threadIdx.x & 63);
     bool visit = lane < sc.n_clusters;            // (n_clusters = ceil(n_hit / 64) wherever the cooperative scans run)
-    if (visit) {
-        const float4 c = ((const float4*)sc.clusters)[2 * lane], h = ((const float4*)sc.clusters)[2 * lane + 1];
-        const float ax = fabsf(rd.x), ay = fabsf(rd.y), az = fabsf(rd.z);
-        const float ox = c.x - ro.x, oy = c.y - ro.y, oz = c.z - ro.z;
-        const float fx = fabsf(ox) + h.x, fy = fabsf(oy) + h.y, fz = fabsf(oz) + h.z;
-        const float dd = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z, D2 = fx * fx + fy * fy + fz * fz;
-        bool usable = dd >= 1e-6f && dd <= 1e6f && D2 >= 1e-12f && D2 <= 1e24f;
-        if (c.w != 0.0f) usable = usable && ax > 1e-12f && ay > 1e-12f && az > 1e-12f;
-        if (usable) {
-            const float m = sqrtf(D2) * 0.01f;
-            const float Hx = h.x + m, Hy = h.y + m, Hz = h.z + m;
-            bool miss = (ox > Hx && rd.x <= 0.0f) || (ox < -Hx && rd.x >= 0.0f)
-                     || (oy > Hy && rd.y <= 0.0f) || (oy < -Hy && rd.y >= 0.0f)
-                     || (oz > Hz && rd.z <= 0.0f) || (oz < -Hz && rd.z >= 0.0f);
-            miss = miss || fabsf(oy * rd.z - oz * rd.y) > Hy * az + Hz * ay
-                        || fabsf(oz * rd.x - ox * rd.z) > Hx * az + Hz * ax
-                        || fabsf(ox * rd.y - oy * rd.x) > Hx * ay + Hy * ax;
-            visit = !miss;
-        }
-    }
+    if (visit) visit = cluster_may_hit(((const float4*)sc.clusters)[2 * lane], ((const float4*)sc.clusters)[2 * lane + 1], ro, rd);
     return __ballot(visit);
 }
 
@@ -831,6 +832,33 @@ __device__ __forceinline__ void wavelist_offer(WaveList& wl, int i, bool wanted)
         if (wl.n < 64) { if ((int)(threadIdx.x & 63) == wl.n) wl.items = i; ++wl.n; }
         else wl.full = true;
     }
+}
+
+// The list in ascending order of its items (closest-hit queries walk it with the sequential rule: scene order).
+__device__ __forceinline__ void wavelist_sort(WaveList& wl)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    int rank = 0;
+    for (int e = 0; e < wl.n; ++e) rank += __builtin_amdgcn_readlane(wl.items, e) < wl.items;       // (items are distinct)
+    int sorted = 0;
+    for (int e = 0; e < wl.n; ++e) {
+        const int v = __builtin_amdgcn_readlane(wl.items, e), r = __builtin_amdgcn_readlane(rank, e);
+        if (lane == r) sorted = v;
+    }
+    wl.items = sorted;
+}
+
+// Which hittables a wave has listed already, one bit each: lane l holds hittables 64 l .. 64 l + 63 (RT_MAX_HITTABLES = 4096).
+struct WaveBits { unsigned long long bits; };
+__device__ __forceinline__ bool wavebits_test(const WaveBits& wb, int i)
+{
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)wb.bits, i >> 6);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(wb.bits >> 32), i >> 6);
+    return ((((unsigned long long)hi << 32) | lo) >> (i & 63)) & 1ull;
+}
+__device__ __forceinline__ void wavebits_set(WaveBits& wb, int i)
+{
+    if ((int)(threadIdx.x & 63) == (i >> 6)) wb.bits |= 1ull << (i & 63);
 }
 
 // closest_hit / closest_hit_primary over a candidate list

@@ -38,6 +38,10 @@ constexpr int BLOCK = 256;
 #ifndef RT_DIRECT_BATCH
 #define RT_DIRECT_BATCH 4
 #endif
+// scenes with at least this many hittables: direct_kernel<.., BIG>
+#ifndef RT_DIRECT_BIG
+#define RT_DIRECT_BIG 256
+#endif
 #ifndef RT_LISTED_WAVES
 #define RT_LISTED_WAVES 4
 #endif
@@ -243,9 +247,12 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
     return o;
 }
 
+// HREC false (direct_kernel on large scenes): the hittables stay in global memory -- wave-uniform reads go through
+// scalar loads anyway (urec), the few per-lane ones (the winner's record) through the vector cache.
+template <bool HREC = true>
 __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, SceneLds& sc, float*& lds_free)
 {
-    const int nrec = 2 * a.n_hit;
+    const int nrec = HREC ? 2 * a.n_hit : 0;
     float4* l_hrec = lds;
     float4* l_lights = l_hrec + nrec;
     float* l_mats = (float*)(l_lights + a.n_lights);
@@ -256,7 +263,7 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     for (int i = threadIdx.x; i < nm; i += nthreads) l_mats[i] = a.mats[i];
     // per-thread words start on the next 16-byte boundary
     lds_free = l_mats + ((nm + 3) & ~3);
-    sc.hrec = l_hrec; sc.lights = l_lights; sc.mats = l_mats;
+    sc.hrec = HREC ? l_hrec : a.hrec; sc.lights = l_lights; sc.mats = l_mats;
     sc.n_hit = a.n_hit; sc.n_lights = a.n_lights;
     sc.khrec = (kptr4)a.hrec; sc.klights = (kptr4)a.lights; sc.kprim = (kptr4)a.prim;
     sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0;
@@ -569,13 +576,16 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(const unsigned short* __
 // direct_kernel: the per-pixel driver for pixels whose primary rays never bounce.  TraceRay then is: closest hit ->
 // sky (renderer.h:40-50) or one shading (renderer.h:55-66) with multiplier 1 and maxDepth = depth = 1
 // (renderer.h:128-132), so color / vec3(maxDepth) is color / 1 and no random number is drawn.
-template <bool EMISSION, bool HAS_NONSPHERE, bool CULL = (RT_DIRECT_CULL != 0)>
+// BIG (scenes of the cooperative route's size): the hittables are not staged into LDS (more waves per CU), and the
+// candidate lists are built from the clusters some ray of the wave may hit (rt_device.hpp cluster_mask) instead of from
+// the whole scene.
+template <bool EMISSION, bool HAS_NONSPHERE, bool CULL = (RT_DIRECT_CULL != 0), bool BIG = false>
 __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
     SceneLds sc;
     float* lds_free;
-    stage_scene(a, lds, sc, lds_free);
+    stage_scene<!BIG>(a, lds, sc, lds_free);
 
     const PixelId p = tiled_pixel(a);
     const size_t o = (size_t)p.x + (size_t)p.r * a.width;
@@ -592,7 +602,82 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
     // sample's queries run over the lists.
     WaveList prim, occl;
     wavelist_init(prim); wavelist_init(occl);
-    if (CULL) {
+    if (CULL && BIG) {
+        if (__ballot(mine) == 0ull) return;
+        typedef const float __attribute__((address_space(4)))* kptrf;
+        typedef const unsigned int __attribute__((address_space(4)))* kptru;
+        const kptrf kcl = (kptrf)a.clusters;
+        const kptru korder = (kptru)a.order;
+        auto box = [&](int c, float4& cb, float4& ch) {
+            cb = make_float4(kcl[8 * c + 0], kcl[8 * c + 1], kcl[8 * c + 2], kcl[8 * c + 3]);
+            ch = make_float4(kcl[8 * c + 4], kcl[8 * c + 5], kcl[8 * c + 6], kcl[8 * c + 7]);
+        };
+        for (int c = 0; c < a.n_clusters; ++c) {
+            float4 cb, ch;
+            box(c, cb, ch);
+            bool may = false;
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k)
+                may = may || cluster_may_hit(cb, ch, origin, mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]));
+            if (__ballot(may && mine) == 0ull) continue;
+            const int end = 64 * c + 64 < sc.n_hit ? 64 * c + 64 : sc.n_hit;
+            for (int slot = 64 * c; slot < end; ++slot) {
+                const int i = (int)korder[slot];
+                float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
+                bool any = false;
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {
+                    v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+                    float fa = 4.0f * dot(rd, rd);
+                    v3 inv = mk(0, 0, 0);
+                    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    float t;
+                    if (!HAS_NONSPHERE) {
+                        f32x4 q = sc.kprim[i];
+                        any = any || sphere_hit_oc(mk(q.x, q.y, q.z), q.w, rd, fa, t);
+                    } else {
+                        any = any || hittable_hit<HAS_NONSPHERE>(r0, r1, origin, rd, fa, inv, t);
+                    }
+                }
+                wavelist_offer(prim, i, any && mine);
+            }
+        }
+        if (!prim.full) {
+            wavelist_sort(prim);
+            WaveBits listed; listed.bits = 0ull;
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+                float dist;
+                int bi = closest_hit_listed<HAS_NONSPHERE, true>(sc, prim, origin, rd, dist);
+                const bool hit = mine && bi >= 0;
+                if (__ballot(hit) == 0ull) continue;
+                v3 pos = mk(0, 0, 0);
+                if (hit) { Hit h = hit_record<!HAS_NONSPHERE>(sc, bi, origin, rd, dist); pos = h.position + h.normal * 0.005f; }
+                for (int j = 0; j < sc.n_lights; ++j) {
+                    int type; float ldist;
+                    v3 l = light_direction(sc, j, pos, type, ldist);
+                    float fa = 4.0f * dot(l, l);
+                    v3 inv = mk(0, 0, 0);
+                    if (HAS_NONSPHERE) inv = mk(1.0f / l.x, 1.0f / l.y, 1.0f / l.z);
+                    for (int c = 0; c < a.n_clusters; ++c) {
+                        float4 cb, ch;
+                        box(c, cb, ch);
+                        if (__ballot(hit && cluster_may_hit(cb, ch, pos, l)) == 0ull) continue;
+                        const int end = 64 * c + 64 < sc.n_hit ? 64 * c + 64 : sc.n_hit;
+                        for (int slot = 64 * c; slot < end; ++slot) {
+                            const int i = (int)korder[slot];
+                            if (wavebits_test(listed, i)) continue;                  // one list for all rays and lights
+                            float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
+                            bool o = hit && ((type == L_DIR) ? occluder_hit<HAS_NONSPHERE, false, false>(r0, r1, pos, l, fa, inv, 0.0f)
+                                                             : occluder_hit<HAS_NONSPHERE, false, true>(r0, r1, pos, l, fa, inv, ldist));
+                            if (__ballot(o) != 0ull) { wavelist_offer(occl, i, true); wavebits_set(listed, i); }
+                        }
+                    }
+                }
+            }
+        }
+    } else if (CULL) {
         for (int i = 0; i < sc.n_hit; ++i) {
             float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
             bool any = false;
@@ -1487,6 +1572,12 @@ hipError_t rt_launch_classify(const KernelArgs& a, const LaunchTraits& t, unsign
 hipError_t rt_launch_direct(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
 {
     const int tiles = a.tiles_x * a.tiles_y;
+    if (RT_DIRECT_CULL && a.n_hit >= RT_DIRECT_BIG && a.clusters && a.order) {
+        // large scenes: no hittables in LDS, candidate lists from the clusters
+        const size_t lds = rt_launch_lds_bytes(0, a.n_lights, a.n_mat);
+        if (t.emission) return t.nonsphere ? launch_with_lds(direct_kernel<true, true, true, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<true, false, true, true>, a, tiles, lds, stream);
+        return t.nonsphere ? launch_with_lds(direct_kernel<false, true, true, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<false, false, true, true>, a, tiles, lds, stream);
+    }
     const size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
     if (t.emission) return t.nonsphere ? launch_with_lds(direct_kernel<true, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<true, false>, a, tiles, lds, stream);
     return t.nonsphere ? launch_with_lds(direct_kernel<false, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<false, false>, a, tiles, lds, stream);
