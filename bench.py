@@ -346,13 +346,15 @@ def main():
             ex = pf["executed_flops"] / (kms * 1e-3) / 1e12
             roof.update({"achieved": round(issue, 1), "frac": round(issue / peak_issue, 4), "valu_issue_frac": round(issue / peak_issue, 4),
                          "executed_flops": pf["executed_flops"], "executed_tflops": round(ex, 2), "executed_frac": round(ex / PEAK_FP32_TFLOPS, 4),
+                         "timed_region_valu_issue_frac": round(pf["valu_wave_instructions"] / sec_per_step / 1e9 / peak_issue, 4),
                          "fma_share": round(pf["fma_share_of_fp32_instructions"], 4), "lane_utilisation": round(pf["lane_utilisation"], 4),
                          "traffic": int(pf["hbm_bytes"]), "traffic_note": "HBM bytes of one frame, 2 x FETCH_SIZE + WRITE_SIZE over its kernels; "
                          "algorithmic bytes: %d (3 B per pixel)" % (3 * W * H), "pmc": pmc_path})
         roof.update({"algorithmic_flops": flops, "algorithmic_tflops": round(algorithmic, 3), "algorithmic_frac": round(algorithmic / PEAK_FP32_TFLOPS, 4),
                      "peak_fp32_tflops": PEAK_FP32_TFLOPS, "timed_region_algorithmic_frac": round(whole_region / PEAK_FP32_TFLOPS, 4),
                      "note": "frac = VALU issue fraction of a frame: executed wave64 VALU instructions (rocprofv3 --pmc SQ_INSTS_VALU, "
-                             "profiles/) / kernel_ms / peak issue rate; kernel_ms = " + basis + ". executed_* = FP32 operations the "
+                             "profiles/) / kernel_ms / peak issue rate; kernel_ms = " + basis + ". timed_region_valu_issue_frac = the "
+                             "same instructions / ms_per_step (the timed region as a whole, host gaps included). executed_* = FP32 operations the "
                              "kernels execute (add + mul + trans + 2 x fma wave instructions x 64 x lane utilisation): nothing is "
                              "contracted (bit parity), so 0.5 of the FMA peak is the ceiling. algorithmic_* = SURVEY 8d flop table x the "
                              "reference algorithm's query tallies: work the kernels partly avoid (candidate lists, shadow pruning), "
