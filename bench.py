@@ -44,8 +44,8 @@ def _frames_in_flight_arg(argv):
     return fif if fif else DEFAULT_IN_FLIGHT
 
 
-DEFAULT_IN_FLIGHT = 8
-HW_QUEUES = "16"
+DEFAULT_IN_FLIGHT = 16
+HW_QUEUES = os.environ.get("RT_HW_QUEUES", "16")
 if _frames_in_flight_arg(sys.argv[1:]) > 1:
     os.environ["GPU_MAX_HW_QUEUES"] = HW_QUEUES
 
@@ -203,6 +203,12 @@ def main():
         r.upload_scene(scene)
     rt = rts[0]
     consumer = ra.Renderer(local_rank)       # gathers and reassembles: a context (stream) of its own, beside the producers'
+    # frames rendered one at a time (warm-up, latency, the kernel span the roofline object prices) are not a sequence:
+    # they run without RT_FLAG_SEQUENCE, on a context of their own (created last: its streams are idle in the timed region)
+    rt_solo = rt
+    if in_flight > 1:
+        rt_solo = ra.Renderer(local_rank)
+        rt_solo.upload_scene(scene)
     comm, gather_group = None, None
     if world > 1 and gather_mode == "rt":
         idt = torch.zeros(ra._abi.RT_COMM_ID_BYTES, dtype=torch.uint8, device=rdev)
@@ -226,6 +232,7 @@ def main():
     rpr = bands.rows_per_rank(H, BAND_ROWS, world)
     seq = ra._abi.RT_FLAG_SEQUENCE if in_flight > 1 else 0          # several frames in flight on this GPU
     p = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank, flags=args.flags | seq)
+    p_solo = bands.band_params(rt_solo, W, H, samples, depth, seed, BAND_ROWS, world, rank, flags=args.flags)
     blocks = [torch.zeros((rpr, W, 3), dtype=torch.uint8, device=dev) for _ in range(in_flight * (2 if in_flight > 1 else 1))]
     block = blocks[0]
     torch.cuda.synchronize()        # the library renders on its own stream: the zero fill must have landed
@@ -237,6 +244,11 @@ def main():
             kernel_ms.append(rt.last_kernel_ms)
             device_ms.append(rt.last_device_ms)
 
+    def render_solo(worker, out, k):
+        rt_solo.render_rows(cam, p_solo, out)
+        kernel_ms.append(rt_solo.last_kernel_ms)
+        device_ms.append(rt_solo.last_device_ms)
+
     pipe = FramePipeline(render, blocks, H, BAND_ROWS, consumer, group=gather_group, workers=in_flight, comm=comm)
 
     def sync():
@@ -245,7 +257,7 @@ def main():
         torch.cuda.synchronize()
 
     # warm-up: W frames one at a time, then every context once
-    solo = FramePipeline(render, blocks[:1], H, BAND_ROWS, consumer, group=gather_group, workers=1, comm=comm)
+    solo = FramePipeline(render_solo if in_flight > 1 else render, blocks[:1], H, BAND_ROWS, consumer, group=gather_group, workers=1, comm=comm)
     for _ in range(args.warmup):
         solo.run(1)
     if in_flight > 1:
@@ -391,6 +403,8 @@ def main():
     consumer.close()
     for r in rts:
         r.close()
+    if rt_solo is not rt:
+        rt_solo.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -107,10 +107,24 @@ static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 static std::mutex g_scratch_mutex;
 static unsigned char* g_scratch_ptr[RT_MAX_DEVICES];
 
+// A failing call leaves the entry point at once; work already queued on the context's streams (kernels, copies into
+// the caller's frame or into locals of the returning function) must not outlive it.
+static void drain_streams(rt_ctx* ctx)
+{
+    if (ctx->stream)  (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+}
+
+// streams a context with RT_FLAG_SEQUENCE works on: 1 (listed kernels in front of the direct kernel) or 2 (beside it)
+#ifndef RT_SEQ_STREAMS_DEFAULT
+#define RT_SEQ_STREAMS_DEFAULT 1
+#endif
+
 #define HIP_TRY(ctx, expr)                                   \
     do {                                                     \
         hipError_t e__ = (expr);                             \
-        if (e__ != hipSuccess) { (ctx)->last_hip = (int)e__; return RT_ERR_HIP; } \
+        if (e__ != hipSuccess) { (ctx)->last_hip = (int)e__; drain_streams(ctx); return RT_ERR_HIP; } \
     } while (0)
 
 namespace {
@@ -253,12 +267,11 @@ int rt_create(rt_ctx** out, int device_ordinal)
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->evm);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_list, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gen, hipEventDisableTiming);
-    // (stream3 is created when the steady / rest split first runs: HIP deals streams to its hardware queues as they are
-    // created, and callers with many contexts in flight -- RT_FLAG_SEQUENCE, two streams each -- should not have idle
-    // third streams pushing busy ones onto shared queues)
+    // (stream2 / stream3 are created when a frame first needs them: HIP deals streams to its hardware queues as they are
+    // created, and callers with many contexts in flight -- RT_FLAG_SEQUENCE -- should not have idle streams pushing
+    // busy ones onto shared queues)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_rest, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, RT_DEV_STATE_BYTES);
     if (e == hipSuccess && device_ordinal < RT_MAX_DEVICES) {
@@ -582,7 +595,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
         // stream; all other pixels need no RNG, stack or scratch and go to the direct kernel.
         const bool bounces = ctx->any_bounce && p->max_depth >= 1;       // renderer.h:68: depth 1 <= maxTotalDepth
         unsigned int n_listed = 0;
-        bool rest = false;
+        bool rest = false, second = false, timed = false;
         if (bounces) {
             unsigned int* list;
             if (no_alloc) {
@@ -655,22 +668,34 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     double min_work = RT_HEAVY_MIN_WORK / (per_bounce > 1.0 ? per_bounce : 1.0);
                     g2.heavy_min_work = force ? 0u : (unsigned int)(min_work < 1.0 ? 1.0 : min_work);
                 }
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_list, 0));
+                // Frames in flight (RT_FLAG_SEQUENCE): the listed kernels go onto the context's one stream, in front of the
+                // direct kernel -- a frame's own kernels then run one after the other, the kernels of the other frames in
+                // flight beside them.  HIP deals streams to hardware queues as they are created; a context that never needs
+                // a second stream never creates one, so N contexts in flight are N busy queues.
+                static const int seq_streams = getenv("RT_SEQ_STREAMS") ? atoi(getenv("RT_SEQ_STREAMS")) : RT_SEQ_STREAMS_DEFAULT;
+                const bool sequence = g2.heavy_cap > 0 && !coop && !rays && (p->flags & RT_FLAG_SEQUENCE) != 0;
+                hipStream_t s2 = ctx->stream;
+                if (!(sequence && seq_streams == 1)) {
+                    if (!ctx->stream2) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+                    s2 = ctx->stream2;
+                    HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_list, 0));
+                }
                 if (coop) {
-                    HIP_TRY(ctx, rt_launch_coop(g2, tg, ctx->stream2));
+                    HIP_TRY(ctx, rt_launch_coop(g2, tg, s2));
                 } else if (rays) {
-                    HIP_TRY(ctx, rt_launch_rays(g2, tg, ctx->stream2));
-                } else if (g2.heavy_cap > 0 && (p->flags & RT_FLAG_SEQUENCE)) {
-                    // frames in flight: one launch owns the whole list (one stream and one dispatch less per frame; the
-                    // split below buys latency for a frame on its own)
+                    HIP_TRY(ctx, rt_launch_rays(g2, tg, s2));
+                } else if (sequence) {
+                    // one launch owns the whole list (one dispatch less per frame; the split below buys latency for a
+                    // frame on its own)
                     g2.listed_mode = RT_MODE_ALL;
-                    HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream2));
-                    HIP_TRY(ctx, rt_launch_heavy(g2, tg, ctx->stream2));
+                    if (s2 == ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
+                    HIP_TRY(ctx, rt_launch_render(g2, tg, s2));
+                    HIP_TRY(ctx, rt_launch_heavy(g2, tg, s2));
                 } else if (g2.heavy_cap > 0) {
                     // the steady long pixels: first samples, hand-over, heavy kernel, resume kernel ...
                     g2.listed_mode = RT_MODE_STEADY;
-                    HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream2));
-                    HIP_TRY(ctx, rt_launch_heavy(g2, tg, ctx->stream2));
+                    HIP_TRY(ctx, rt_launch_render(g2, tg, s2));
+                    HIP_TRY(ctx, rt_launch_heavy(g2, tg, s2));
                     // ... and beside them all other listed pixels
                     g2.listed_mode = RT_MODE_REST;
                     if (!ctx->stream3) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
@@ -679,14 +704,15 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_rest, ctx->stream3));
                     rest = true;
                 } else {
-                    HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream2));
+                    HIP_TRY(ctx, rt_launch_render(g2, tg, s2));
                 }
-                HIP_TRY(ctx, hipEventRecord(ctx->ev_gen, ctx->stream2));
+                if (s2 != ctx->stream) { HIP_TRY(ctx, hipEventRecord(ctx->ev_gen, s2)); second = true; }
+                else timed = true;                               // (evm already stands in front of the listed kernels)
             }
         }
-        HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
+        if (!timed) HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
         if (n_listed < npix) HIP_TRY(ctx, rt_launch_direct(a, t, ctx->stream));
-        if (n_listed > 0) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gen, 0));
+        if (second) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gen, 0));
         if (rest) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_rest, 0));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
