@@ -25,8 +25,44 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 builders = [scenes.default4, scenes.random10, scenes.glass_mirror, scenes.plane_scene, scenes.cube_scene,
             scenes.point_light_scene, scenes.degenerate_scene, scenes.nan_scene,
             lambda: scenes.many_objects(n=300, n_lights=4, seed=int(rs.randint(1, 1000)))]
+
+
+def large_scene():
+    """many_objects with what the cluster culling of the large-scene kernels has to get right at random: the scene
+    scaled about the camera (distances from 1e-7 to 1e14), directional lights with zero components, planes."""
+    sc = scenes.many_objects(n=int(rs.randint(257, 900)), n_lights=int(rs.randint(1, 9)), seed=int(rs.randint(1, 1000)))
+    if rs.randint(3) == 0:
+        sc.lights = []
+        for _ in range(int(rs.randint(1, 4))):
+            d = rs.choice([0.0, 0.0, 1.0, -1.0, 0.3], size=3)
+            d[1] = -1.0 - rs.randint(2)
+            sc.dirlight(tuple(float(v) for v in d))
+    if rs.randint(4) == 0:
+        sc.plane((0.0, float(rs.uniform(-1.0, 0.2)), 0.0), (0.0, 1.0, 0.0), int(rs.randint(4)))
+    if rs.randint(2) == 0:
+        k = float(rs.choice([1e-7, 1e-4, 1e-2, 30.0, 1e4, 1e8, 1e11, 1e14]))
+        p0 = oracle_lib.camera(sc, 64, 36)[0:3].astype(np.float64)
+        at = lambda v: tuple(p0 + k * (np.array(v, dtype=np.float64) - p0))
+        out = scenes.Scene(name="%s_x%g" % (sc.name, k))
+        out.materials = list(sc.materials)
+        for t, a, b, r, m in sc.hittables:
+            if t == scenes.SPHERE:
+                out.sphere(at(a), r * k, m)
+            elif t == scenes.CUBE:
+                out.cube(at(a), tuple(k * np.array(b, dtype=np.float64)), m)
+            else:
+                out.plane(at(a), b, m)
+        for t, v in sc.lights:
+            if t == scenes.POINTLIGHT:
+                out.pointlight(at(v))
+            else:
+                out.dirlight(v)
+        sc = out
+    return sc
+
+
 if os.environ.get("RT_STRESS_LARGE"):
-    builders = [lambda: scenes.many_objects(n=int(rs.randint(257, 900)), n_lights=int(rs.randint(1, 9)), seed=int(rs.randint(1, 1000)))]
+    builders = [large_scene]
 rt = ra.Renderer(0)
 t_end = time.time() + budget
 n_cases = n_pixels = 0

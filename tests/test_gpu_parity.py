@@ -129,6 +129,66 @@ def test_large_scene_cooperative_route(rt):
     assert np.array_equal(rgb, want_rgb) and np.array_equal(em.view(np.uint32), want_em.view(np.uint32))
 
 
+def _scaled_about_camera(sc, k):
+    """The scene scaled by k about the camera's position (the reference's camera does not move): the same view, with
+    every distance the primitive tests see multiplied by k."""
+    p0 = oracle_lib.camera(sc, 64, 36)[0:3].astype(np.float64)
+    out = scenes.Scene(name="%s_x%g" % (sc.name, k))
+    out.materials = list(sc.materials)
+    out.fov, out.znear, out.zfar = sc.fov, sc.znear, sc.zfar
+    at = lambda v: tuple(p0 + k * (np.array(v, dtype=np.float64) - p0))
+    for t, a, b, r, m in sc.hittables:
+        if t == scenes.SPHERE:
+            out.sphere(at(a), r * k, m)
+        elif t == scenes.CUBE:
+            out.cube(at(a), tuple(k * np.array(b, dtype=np.float64)), m)
+        else:
+            out.plane(at(a), b, m)
+    for t, v in sc.lights:
+        if t == scenes.POINTLIGHT:
+            out.pointlight(at(v))
+        else:
+            out.dirlight(v)
+    return out
+
+
+def test_large_scene_culling_edge_cases(rt):
+    """The large-scene kernels skip whole groups of 64 hittables when the ray certainly misses the group's box
+    (rt_device.hpp cluster_mask).  Cases at the edges of that argument, each against the oracle, bytes and bits:
+    axis-aligned light directions (zero components: 1 / 0 in cube.h:15), planes and NaN / inverted / zero-size
+    hittables among the 300 (unbounded or degenerate boxes), and the scene scaled about the camera up to where the
+    guards switch the culling off (distances beyond 1e12 and below 1e-6)."""
+    def check(sc, W=64, H=36, samples=2, depth=6, seed=3):
+        want_rgb, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, seed, threads=8)
+        rt.upload_scene(sc)
+        rgb, em, _ = rt.render(W, H, samples, depth, seed, emission=True)
+        assert np.array_equal(rgb, want_rgb), sc.name
+        assert np.array_equal(em.view(np.uint32), want_em.view(np.uint32)), sc.name
+
+    sc = scenes.many_objects(n=300, n_lights=0, seed=17)
+    sc.dirlight((0.0, -1.0, 0.0))
+    sc.dirlight((1.0, -1.0, 0.0))
+    sc.dirlight((0.0, -1.0, -1.0))
+    sc.name = "axis_lights"
+    check(sc)
+
+    sc = scenes.many_objects(n=300, n_lights=3, seed=19)
+    sc.plane((0.0, -0.25, 0.0), (0.0, 1.0, 0.0), 1)
+    sc.plane((0.0, 0.0, -70.0), (0.0, 0.0, 1.0), 3)
+    sc.cube((2.0, 1.5, -6.0), (-1.0, -1.0, -1.0), 2)              # corners the other way round
+    sc.cube((-3.0, 0.0, -5.0), (0.0, 1.0, 1.0), 1)                # flat
+    sc.sphere((0.5, 0.5, -4.0), 0.0, 2)
+    sc.sphere((-1.5, 0.6, -4.0), -0.6, 3)                         # sphere.h:19 squares the radius
+    sc.sphere((3.0, 0.5, -8.0), float("inf"), 1)
+    sc.cube((float("nan"), 0.0, -9.0), (1.0, 1.0, 1.0), 2)
+    sc.name = "planes_and_degenerates"
+    check(sc)
+
+    base = scenes.many_objects(n=300, n_lights=4, seed=29)
+    for k in (1e5, 1e9, 1e11, 1e14, 1e-4, 1e-7):
+        check(_scaled_about_camera(base, k))
+
+
 def test_large_scene_more_pixels_than_resident_waves(rt):
     """coop_kernel's grid is only as large as fits the GPU at once; its waves take pixels from a queue until the list is
     used up.  A frame with several times more bounce pixels than resident waves (16 384 at most: 4 workgroups of 8
