@@ -37,28 +37,68 @@ __global__ __launch_bounds__(256) void glow_downsample_kernel(const float4* __re
     dst[(size_t)x + (size_t)y * dW] = make_float4(c0 * percStep, c1 * percStep, c2 * percStep, strength);
 }
 
-// src/main.cpp:125-156: taps in the reference's order (kX outer, kY inner), clamped coordinates
-__global__ __launch_bounds__(256) void glow_blur_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int w, int h, int size,
-                                                         const float* __restrict__ kernel)
+// src/main.cpp:125-156: taps in the reference's order (kX outer, kY inner), clamped coordinates.  A T x T tile of
+// level pixels per workgroup; the taps come from LDS: for a run of `cw` consecutive kX the workgroup stages the
+// (T + 2 size) x (T + cw - 1) source pixels its threads will read, coordinates clamped as the reference clamps them,
+// and every thread adds its taps of that run in the reference's order (runs ascending, kX ascending, kY ascending: the
+// same sequence of float additions per output pixel).  One global load per staged pixel instead of one per tap: the
+// 4K frame's four levels read 2.2e9 taps.
+template <int T>
+__global__ __launch_bounds__(T * T) void glow_blur_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int w, int h, int size,
+                                                           const float* __restrict__ kernel, int cw)
 {
-    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (x >= w || y >= h) return;
+    extern __shared__ float4 tile[];
+    // the run's weights behind the tile (LDS like the taps: scalar loads would share the LDS reads' wait counter and
+    // return out of order, so every wait would be a wait for everything)
+    float* wts = (float*)(tile + (T + 2 * size) * (T + cw - 1));
+    const int tx = threadIdx.x % T, ty = threadIdx.x / T;
+    const int bx = blockIdx.x * T, by = blockIdx.y * T;
+    const int x = bx + tx, y = by + ty;
     const kptrf kk = (kptrf)kernel;
     const int n = 2 * size + 1;
+    const int rows = T + 2 * size, pitch = T + cw - 1;
     float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, strength = 0.0f;
     int count = 0;
-    for (int kX = -size; kX <= size; ++kX) {
-        int newX = x + kX; newX = newX < 0 ? 0 : newX; newX = newX < w - 1 ? newX : w - 1;
-        const kptrf krow = kk + (size_t)(kX + size) * n + size;
-#pragma unroll 8
-        for (int kY = -size; kY <= size; ++kY) {                 // (unrolled: eight taps' loads in flight, added in order)
-            int newY = y + kY; newY = newY < 0 ? 0 : newY; newY = newY < h - 1 ? newY : h - 1;
-            const float k = krow[kY];
-            const float4 p = src[(size_t)newX + (size_t)newY * w];
-            e0 += p.x * k; e1 += p.y * k; e2 += p.z * k;
-            if (p.w > 0) { ++count; strength += p.w; }
+    for (int k0 = -size; k0 <= size; k0 += cw) {
+        const int run = k0 + cw - 1 <= size ? cw : size - k0 + 1;
+        const int cols = T + run - 1;
+        __syncthreads();                                          // (the previous run's taps have been read)
+        // (thread (tx, ty) stages columns tx, tx + T, .. of rows ty, ty + T, ..: four rows' loads in flight)
+        for (int c = tx; c < cols; c += T) {
+            int sx = bx + k0 + c; sx = sx < 0 ? 0 : sx; sx = sx < w - 1 ? sx : w - 1;
+#pragma unroll 4
+            for (int r = ty; r < rows; r += T) {
+                int sy = by - size + r; sy = sy < 0 ? 0 : sy; sy = sy < h - 1 ? sy : h - 1;
+                tile[r * pitch + c] = src[(size_t)sx + (size_t)sy * w];
+            }
+        }
+        for (int i = threadIdx.x; i < run * n; i += T * T) wts[i] = kk[(size_t)(k0 + size) * n + i];
+        __syncthreads();
+        for (int kX = k0; kX < k0 + run; ++kX) {
+            const float* krow = wts + (kX - k0) * n;
+            const float4* col = tile + ty * pitch + tx + (kX - k0);
+            // j = kY + size; eight taps' reads in flight, added in order
+            int j = 0;
+            for (; j + 8 <= n; j += 8) {
+                float4 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = col[(j + u) * pitch];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float k = krow[j + u];
+                    e0 += p[u].x * k; e1 += p[u].y * k; e2 += p[u].z * k;
+                    if (p[u].w > 0) { ++count; strength += p[u].w; }
+                }
+            }
+            for (; j < n; ++j) {
+                const float k = krow[j];
+                const float4 p = col[j * pitch];
+                e0 += p.x * k; e1 += p.y * k; e2 += p.z * k;
+                if (p.w > 0) { ++count; strength += p.w; }
+            }
         }
     }
+    if (x >= w || y >= h) return;
     if (count > 0) strength /= count;
     dst[(size_t)x + (size_t)y * w] = make_float4(e0, e1, e2, strength);
 }
@@ -118,7 +158,22 @@ hipError_t rt_launch_glow_downsample(const void* src, int srcW, void* dst, int d
 hipError_t rt_launch_glow_blur(const void* src, void* dst, int w, int h, int size, const float* kernel, hipStream_t stream)
 {
     if (w <= 0 || h <= 0) return hipSuccess;
-    hipLaunchKernelGGL(glow_blur_kernel, dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, stream, (const float4*)src, (float4*)dst, w, h, size, kernel);
+    // small levels (large windows) in 8 x 8 tiles: four times the workgroups for the few pixels they have
+    const int T = size >= 32 ? 8 : 16;
+    const int rows = T + 2 * size, n = 2 * size + 1;
+    // columns of kX per staged run: tile (rows x (T + cw - 1) pixels of 16 B) + weights (cw x n floats) within an LDS
+    // budget that lets every workgroup of the level be resident at once where that is possible (a thread's taps are one
+    // serial chain of additions: a second round of workgroups doubles the level's time), 12 .. 48 KiB
+    const int blocks = ((w + T - 1) / T) * ((h + T - 1) / T);
+    const int per_cu = (blocks + 255) / 256;
+    int budget = (T != 8 || per_cu > 8) ? 48 * 1024 : 160 * 1024 / per_cu - 1024;   // (the large levels' 256-thread workgroups: fewer, longer runs measured faster)
+    budget = budget < 12 * 1024 ? 12 * 1024 : budget > 48 * 1024 ? 48 * 1024 : budget;
+    int cw = (budget - rows * (T - 1) * 16) / (rows * 16 + n * 4);
+    cw = cw < 1 ? 1 : cw > n ? n : cw;
+    const size_t lds = (size_t)rows * (size_t)(T + cw - 1) * 16 + (size_t)cw * n * 4;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;             // (size <= 128: rt_apply_glow refuses larger windows)
+    if (T == 8) hipLaunchKernelGGL(glow_blur_kernel<8>, dim3((w + 7) / 8, (h + 7) / 8), dim3(64), lds, stream, (const float4*)src, (float4*)dst, w, h, size, kernel, cw);
+    else        hipLaunchKernelGGL(glow_blur_kernel<16>, dim3((w + 15) / 16, (h + 15) / 16), dim3(256), lds, stream, (const float4*)src, (float4*)dst, w, h, size, kernel, cw);
     return hipGetLastError();
 }
 
