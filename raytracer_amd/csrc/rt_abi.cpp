@@ -675,11 +675,13 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                 static const int seq_streams = getenv("RT_SEQ_STREAMS") ? atoi(getenv("RT_SEQ_STREAMS")) : RT_SEQ_STREAMS_DEFAULT;
                 const bool sequence = g2.heavy_cap > 0 && !coop && !rays && (p->flags & RT_FLAG_SEQUENCE) != 0;
                 hipStream_t s2 = ctx->stream;
-                if (!(sequence && seq_streams == 1)) {
+                // (rt_render_rows_static creates nothing, streams included: its listed kernel runs in front of the direct one)
+                if (!(sequence && seq_streams == 1) && !no_alloc) {
                     if (!ctx->stream2) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
                     s2 = ctx->stream2;
                     HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_list, 0));
                 }
+                if (s2 == ctx->stream) { HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream)); timed = true; }   // the kernel span starts here
                 if (coop) {
                     HIP_TRY(ctx, rt_launch_coop(g2, tg, s2));
                 } else if (rays) {
@@ -688,7 +690,6 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     // one launch owns the whole list (one dispatch less per frame; the split below buys latency for a
                     // frame on its own)
                     g2.listed_mode = RT_MODE_ALL;
-                    if (s2 == ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
                     HIP_TRY(ctx, rt_launch_render(g2, tg, s2));
                     HIP_TRY(ctx, rt_launch_heavy(g2, tg, s2));
                 } else if (g2.heavy_cap > 0) {
@@ -707,7 +708,6 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     HIP_TRY(ctx, rt_launch_render(g2, tg, s2));
                 }
                 if (s2 != ctx->stream) { HIP_TRY(ctx, hipEventRecord(ctx->ev_gen, s2)); second = true; }
-                else timed = true;                               // (evm already stands in front of the listed kernels)
             }
         }
         if (!timed) HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
