@@ -113,6 +113,9 @@ typedef struct {
 #define RT_FLAG_RAYS_LISTED            32 /* bounce pixels of small scenes a lane per ray, 16 lanes per pixel, each ray
                                            from a guessed place in the pixel's rand() sequence (rays_kernel): same
                                            bytes, shorter latency for a small frame on its own, more work per ray   */
+#define RT_FLAG_FORCE_SOLO             64 /* test hook: every bounce pixel leaves the listed kernel after its first four
+                                           samples for a wave of its own (the route of long pixels whose draw counts
+                                           differ from sample to sample)                                             */
 
 /* Query tallies with the reference's meaning: primary = W*rows*samples*4; closest = TraceRay closest-hit queries
  * (src/renderer.h:40); shadow = hasIntersect / point-light occlusion queries (directionalLight.h:13); tests =

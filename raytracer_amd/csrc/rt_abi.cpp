@@ -34,6 +34,14 @@
 #ifndef RT_HEAVY_MIN_WORK
 #define RT_HEAVY_MIN_WORK 12000u
 #endif
+// draws a pixel with unsteady counts is expected to make in its remaining samples for it to get a wave of its own.
+// 0: the route is off, which is the default -- measured: it shortens the listed kernel but not
+// the frame (glass 1080p alone 171 -> 165 ms at 20000, the wave that renders the longest pixel from its first sample
+// takes 82 ms by itself) and costs throughput with frames in flight (31 -> 39 ms per frame).  RT_SOLO_MIN_WORK in the
+// environment sets it for A/B runs; RT_FLAG_FORCE_SOLO sends every bounce pixel that way (tests).
+#ifndef RT_SOLO_MIN_WORK
+#define RT_SOLO_MIN_WORK 0u
+#endif
 
 struct rt_ctx {
     int device = -1;
@@ -85,9 +93,11 @@ struct rt_ctx {
 #define RT_DEV_WORDS_BYTES (5 * sizeof(unsigned long long) + sizeof(int) * 2)
 // Everything a frame needs zeroed sits in one block behind them, so that one fill per frame does it (under load every
 // small dispatch waits its turn for tens of microseconds): the sample-parallel route's counters (heavy_count,
-// fallback_count, pool words used: 16 bytes), then the pixel classes' histogram and cursor (2 * RT_MAX_KEYS words).
+// fallback_count, pool words used: 16 bytes; solo_count and the solo launch's queue word: 8 bytes + 8 of padding), then
+// the pixel classes' histogram and cursor (2 * RT_MAX_KEYS words).
 #define RT_DEV_HEAVY_AT  RT_DEV_WORDS_BYTES
-#define RT_DEV_HIST_AT   (RT_DEV_HEAVY_AT + 16)
+#define RT_DEV_SOLO_AT   (RT_DEV_HEAVY_AT + 16)
+#define RT_DEV_HIST_AT   (RT_DEV_SOLO_AT + 16)
 #define RT_DEV_STATE_BYTES (RT_DEV_HIST_AT + 2 * RT_MAX_KEYS * sizeof(unsigned int))
 
 // rt_render_rows_static (include/rt_amd.h): the per-frame device state and the pixel classes of a call that may not
@@ -198,6 +208,7 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
     a.keys = nullptr; a.hist = nullptr; a.list = nullptr; a.list_count = 0; a.list_count_dev = nullptr;
     a.fallback_count = nullptr; a.fallback_list = nullptr; a.listed_mode = 0;
     a.heavy_count = nullptr; a.heavy_rec = nullptr; a.heavy_pool = nullptr; a.heavy_pool_used = nullptr;
+    a.solo_list = nullptr; a.solo_count = nullptr; a.solo_cap = 0; a.solo_min_work = 0; a.coop_lds_stack = 0;
     a.heavy_pool_words = 0; a.heavy_cap = 0; a.heavy_min_work = 0;
     a.prim = ctx->d_prim;
     a.order = ctx->d_order;
@@ -652,7 +663,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     if (ctx->heavy_pool_bytes > pool_bytes) pool_bytes = ctx->heavy_pool_bytes;
                     ctx->heavy_pool_bytes = pool_bytes;
                     const size_t pool_words = pool_bytes / 4;
-                    rc = grow(ctx, &ctx->d_heavy, &ctx->heavy_bytes, 16 + 4 * (pool_words + cap * (RT_HEAVY_REC_WORDS + 1)));
+                    rc = grow(ctx, &ctx->d_heavy, &ctx->heavy_bytes, 16 + 4 * (pool_words + cap * (RT_HEAVY_REC_WORDS + 2)));
                     if (rc) return rc;
                     g2.heavy_count = (unsigned int*)(state + RT_DEV_HEAVY_AT);   // zeroed with the counters
                     g2.fallback_count = g2.heavy_count + 1;
@@ -667,7 +678,27 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     const double per_bounce = (double)ctx->n_hit * (1.0 + ctx->n_lights) / 8.0;
                     double min_work = RT_HEAVY_MIN_WORK / (per_bounce > 1.0 ? per_bounce : 1.0);
                     g2.heavy_min_work = force ? 0u : (unsigned int)(min_work < 1.0 ? 1.0 : min_work);
+                    // long pixels whose draw counts differ from sample to sample: a wave each (coop_kernel over solo_list)
+                    static const unsigned int solo_work = getenv("RT_SOLO_MIN_WORK") ? (unsigned int)atoll(getenv("RT_SOLO_MIN_WORK")) : RT_SOLO_MIN_WORK;
+                    const bool force_solo = (p->flags & RT_FLAG_FORCE_SOLO) != 0;
+                    if ((solo_work > 0 || force_solo) && !force && rt_launch_coop_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
+                        g2.solo_list = g2.fallback_list + cap;
+                        g2.solo_count = (unsigned int*)(state + RT_DEV_SOLO_AT);   // zeroed with the counters
+                        g2.solo_cap = (int)cap;
+                        double sw = (double)solo_work / (per_bounce > 1.0 ? per_bounce : 1.0);
+                        g2.solo_min_work = force_solo ? 0u : (unsigned int)(sw < 1.0 ? 1.0 : sw);
+                        if (force_solo) g2.heavy_min_work = 0xffffffffu;          // test hook: no pixel counts as steady
+                    }
                 }
+                // coop_kernel over the pixels the listed kernel hands over: its list and length live on the device
+                auto launch_solo = [&](hipStream_t st) -> hipError_t {
+                    if (!g2.solo_list) return hipSuccess;
+                    KernelArgs g3 = g2;
+                    g3.list = g2.solo_list; g3.list_count = g2.solo_cap; g3.list_count_dev = g2.solo_count;
+                    g3.queue = g2.solo_count + 1;
+                    g3.heavy_cap = 0; g3.solo_list = nullptr;
+                    return rt_launch_coop(g3, tg, st);
+                };
                 // Frames in flight (RT_FLAG_SEQUENCE): the listed kernels go onto the context's one stream, in front of the
                 // direct kernel -- a frame's own kernels then run one after the other, the kernels of the other frames in
                 // flight beside them.  HIP deals streams to hardware queues as they are created; a context that never needs
@@ -692,6 +723,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     g2.listed_mode = RT_MODE_ALL;
                     HIP_TRY(ctx, rt_launch_render(g2, tg, s2));
                     HIP_TRY(ctx, rt_launch_heavy(g2, tg, s2));
+                    HIP_TRY(ctx, launch_solo(s2));
                 } else if (g2.heavy_cap > 0) {
                     // the steady long pixels: first samples, hand-over, heavy kernel, resume kernel ...
                     g2.listed_mode = RT_MODE_STEADY;
@@ -702,6 +734,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     if (!ctx->stream3) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
                     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_list, 0));
                     HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream3));
+                    HIP_TRY(ctx, launch_solo(ctx->stream3));
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_rest, ctx->stream3));
                     rest = true;
                 } else {

@@ -60,6 +60,7 @@ struct SceneLds {
     const unsigned int* slot_of;
     // coop_kernel: boxes (LDS, 8 floats each) of the rounds of 64 slots, for cluster_mask(); 0: none
     const float* clusters; int n_clusters;
+    float4* xstack;       // coop_kernel: this wave's bounce stack in LDS (trace_path), or null: scratch
     // coop_kernel: per-wave candidate lists for the pixel's primary rays and their shadow rays (LDS, ascending indices);
     // a negative count means there is no list
     const unsigned short* cl_prim; int cl_nprim;

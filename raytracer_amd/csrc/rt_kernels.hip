@@ -73,10 +73,17 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
     int sp = 0, pp = 0;
     // coop_kernel: the 64 lanes of the wave hold one path, so one copy of its frames is enough -- lane 0's; the others
     // neither write theirs nor use what they read back
+    // Where LDS has room for it (sc.xstack: this wave's 2 MAXSP + 3 MAXPEND frames) that copy lives there: a pop then
+    // costs an LDS read instead of a trip to the L2.
     constexpr bool ONE_COPY = BATCH == RT_COOP;
     const bool keeper = !ONE_COPY || (threadIdx.x & 63) == 0;
-    auto put = [&](float4* arr, int i, float4 v) { if (keeper) arr[i] = v; };
+    float4* const xs = ONE_COPY ? sc.xstack : nullptr;
+    auto put = [&](float4* arr, int i, float4 v) {
+        if (ONE_COPY && xs) { if (keeper) xs[(arr == stk ? 0 : arr == stk_em ? MAXSP : 2 * MAXSP) + i] = v; }
+        else if (keeper) arr[i] = v;
+    };
     auto get = [&](const float4* arr, int i) -> float4 {
+        if (ONE_COPY && xs) return xs[(arr == stk ? 0 : arr == stk_em ? MAXSP : 2 * MAXSP) + i];       // (every lane reads the one copy)
         float4 v = arr[i];
         if (ONE_COPY) {
             v.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.x)));
@@ -266,7 +273,7 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     sc.hrec = HREC ? l_hrec : a.hrec; sc.lights = l_lights; sc.mats = l_mats;
     sc.n_hit = a.n_hit; sc.n_lights = a.n_lights;
     sc.khrec = (kptr4)a.hrec; sc.klights = (kptr4)a.lights; sc.kprim = (kptr4)a.prim;
-    sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0;
+    sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0; sc.xstack = nullptr;
     sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
     __syncthreads();
 }
@@ -442,6 +449,14 @@ __device__ __forceinline__ bool heavy_handover(const KernelArgs& a, RNG& rng, un
 // (x, y) of the frame = column x of packed output row r.
 // LDS_RNG: the generator's 31 words live in LDS at rng_lds (slot-major) instead of in scratch.  HEAVY: pixels whose
 // first sample shows a long path are handed to heavy_kernel.
+__device__ __forceinline__ bool solo_handover(const KernelArgs& a, unsigned int pixel)
+{
+    const unsigned int k = atomicAdd(a.solo_count, 1u);
+    if (k >= (unsigned int)a.solo_cap) return false;           // (the count may run past the list: those pixels stay where they are)
+    a.solo_list[k] = pixel;
+    return true;
+}
+
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, bool LDS_RNG, int BATCH, bool HEAVY, int STRIDE = BLOCK>
 __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds& sc, float* dirs, unsigned int* rng_lds,
                                              int x, int y, int r, Counters& cnt, bool writer = true)
@@ -481,9 +496,15 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
                 // (the test hook, threshold 0, also hands over pixels whose counts differ: the re-guess path)
                 const bool eligible = guess > 0 && (agree >= RT_HEAVY_AGREE || a.heavy_min_work == 0)
                     && (unsigned long long)guess * (unsigned int)(a.samples - RT_HEAVY_PROBE) >= (unsigned long long)a.heavy_min_work;
-                if (a.listed_mode == RT_MODE_REST) { if (eligible) return; }
+                // Long pixels whose counts differ stay serial, and a lane that walks one holds its wave (and the frame)
+                // for the pixel's whole chain: they leave after these four samples for a wave of their own --
+                // coop_kernel over a.solo_list renders them from their first sample (solo_* in rt_launch.h).
+                const unsigned long long est = ((unsigned long long)c0 + c1 + c2 + c3) * (unsigned int)(a.samples - RT_HEAVY_PROBE) / RT_HEAVY_PROBE;
+                const bool solo = !eligible && a.solo_list != nullptr && est >= (unsigned long long)a.solo_min_work;
+                if (a.listed_mode == RT_MODE_REST) { if (eligible) return; if (solo && solo_handover(a, (unsigned int)o)) return; }
                 else if (eligible) { if (heavy_handover(a, rng, (unsigned int)o, guess, acc_color, acc_em, acc_st)) return; }
                 else if (a.listed_mode == RT_MODE_STEADY) return;
+                else if (solo && solo_handover(a, (unsigned int)o)) return;
             }
         }
     }
@@ -970,11 +991,15 @@ __global__ __launch_bounds__(COOP_WAVES * 64, RT_COOP_MIN_WAVES) void coop_kerne
     // done: every wave therefore takes pixels from a queue (a counter over the list) until the list is used up, and
     // the grid is only as large as fits the GPU at once (rt_launch_coop).
     // (a wave takes at most list_count pixels: the bound is never reached, and no wave can spin for ever)
-    for (unsigned int turn = 0; turn <= (unsigned int)a.list_count; ++turn) {
+    // (the list's length may live on the device -- pixels handed over by the listed kernel in front of this launch --
+    // and may have run past the list's capacity)
+    unsigned int n_list = (unsigned int)a.list_count;
+    if (a.list_count_dev) { const unsigned int d = *a.list_count_dev; n_list = d < n_list ? d : n_list; }
+    for (unsigned int turn = 0; turn <= n_list; ++turn) {
     unsigned int i = 0;
     if (lane == 0) i = atomicAdd(a.queue, 1u);
     i = (unsigned int)__builtin_amdgcn_readfirstlane((int)i);
-    if (i >= (unsigned int)a.list_count) break;
+    if (i >= n_list) break;
     const unsigned int o = a.list[i];
     const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
     const int y = frame_row(a, r);
@@ -985,6 +1010,8 @@ __global__ __launch_bounds__(COOP_WAVES * 64, RT_COOP_MIN_WAVES) void coop_kerne
     // that occlude them, and the primary segment of every sample runs over those two lists instead of the scene.
     unsigned short* lp = (unsigned short*)(lds_free + (12 + 32) * COOP_WAVES) + wave * (2 * COOP_LIST);
     unsigned short* lo = lp + COOP_LIST;
+    // (behind the lists, 16-byte aligned: the waves' bounce stacks, when the launch made room for them)
+    sc.xstack = a.coop_lds_stack ? (float4*)(lds_free + (12 + 32) * COOP_WAVES + COOP_WAVES * COOP_LIST) + (size_t)wave * (2 * MAXSP + 3 * MAXPEND) : nullptr;
     const unsigned long long below = (1ull << lane) - 1ull;
     const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
     primary_directions<COOP_WAVES>(a, dirs, x, y);
@@ -1470,7 +1497,7 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0; sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
+    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0; sc.xstack = nullptr; sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
     v3 ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     float4 r0 = hrec[2 * index], r1 = hrec[2 * index + 1];
     float fa = 4.0f * dot(rd, rd);
@@ -1700,10 +1727,16 @@ static hipError_t launch_coop(K k, const KernelArgs& a, int blocks, size_t lds_b
 }
 
 // coop_kernel over the pixel list: one wave per pixel.
-hipError_t rt_launch_coop(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
+hipError_t rt_launch_coop(const KernelArgs& a0, const LaunchTraits& t, hipStream_t stream)
 {
+    KernelArgs a = a0;
     const int blocks = (a.list_count + COOP_WAVES - 1) / COOP_WAVES;
-    const size_t lds = coop_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+    size_t lds = coop_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+    // The waves' bounce stacks go into LDS when two workgroups still fit a CU with them, or when the scene is small
+    // (the route of long pixels of small scenes: few waves, each a long serial chain of pushes and pops).
+    const size_t stack = (size_t)COOP_WAVES * 16 * (t.deep ? 2 * RT_STACK_DEEP + 3 * RT_PEND_DEEP : 2 * RT_STACK_SHALLOW + 3 * RT_PEND_SHALLOW);
+    a.coop_lds_stack = (lds + stack <= 80 * 1024 || (a.n_hit < 256 && lds + stack <= 160 * 1024)) ? 1 : 0;
+    if (a.coop_lds_stack) lds += stack;
 #define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N)                                \
         return t.deep ? launch_coop(coop_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream)       \
                       : launch_coop(coop_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, stream);

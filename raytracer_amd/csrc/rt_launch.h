@@ -58,6 +58,12 @@ struct KernelArgs {
     unsigned int* fallback_count;// pixels heavy_kernel gave up on ...
     unsigned int* fallback_list; // ... their record indices, for resume_kernel (heavy_cap entries)
     int listed_mode;             // RT_MODE_*: which pixels of the list this launch of the listed kernel owns
+    // long pixels with unsteady draw counts (listed render_kernel -> coop_kernel, one wave per pixel); null: off
+    unsigned int* solo_list;     // solo_cap pixels (indices into the packed output)
+    unsigned int* solo_count;    // pixels handed over (may run past solo_cap: those were not)
+    int solo_cap;
+    int coop_lds_stack;          // coop_kernel: the waves' bounce stacks live in LDS (set by rt_launch_coop)
+    unsigned int solo_min_work;  // hand over when mean draws of the first four samples * (samples left) reaches this
 };
 
 struct LaunchTraits {

@@ -387,6 +387,26 @@ def test_ray_parallel_route_gives_the_same_bytes(rt, name, W, H, samples, depth)
         assert np.array_equal(rgb, want_rgb), (flags, "rgb only")
 
 
+@pytest.mark.parametrize("name,W,H,samples,depth", [("glass_mirror", 96, 54, 16, 12), ("default4", 128, 64, 9, 10), ("cube", 64, 48, 8, 6)])
+def test_solo_route_gives_the_same_bytes(rt, name, W, H, samples, depth):
+    """RT_FLAG_FORCE_SOLO: every bounce pixel leaves the listed kernel after its first four samples and is rendered by a
+    wave of its own (coop_kernel over the hand-over list, its bounce stack in LDS) -- the route of long pixels with
+    unsteady draw counts, off by default.  Same bytes as the oracle, alone and with the sequence hint."""
+    from raytracer_amd import _abi
+    sc = scenes.BUILTIN[name]()
+    want_rgb, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, 5, threads=8)
+    rt.upload_scene(sc)
+    cam = ra.camera35f(sc, W, H)
+    for flags in (_abi.RT_FLAG_FORCE_SOLO, _abi.RT_FLAG_FORCE_SOLO | _abi.RT_FLAG_SEQUENCE):
+        rgb = np.zeros((H, W, 3), np.uint8); em = np.zeros((H, W, 4), np.float32)
+        rt.render_rows(cam, rt.params(W, H, samples, depth, 5, flags=flags), rgb, em)
+        assert np.array_equal(rgb, want_rgb), flags
+        assert np.array_equal(em.view(np.uint32), want_em.view(np.uint32)), flags
+        rgb = np.zeros((H, W, 3), np.uint8)
+        rt.render_rows(cam, rt.params(W, H, samples, depth, 5, flags=flags), rgb, None)
+        assert np.array_equal(rgb, want_rgb), (flags, "rgb only")
+
+
 def test_rows_and_cyclic_bands_are_partition_independent(rt):
     sc = scenes.glass_mirror()
     W, H, samples, depth, seed = 120, 100, 2, 6, 9
