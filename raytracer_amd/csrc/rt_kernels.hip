@@ -519,32 +519,85 @@ __device__ __forceinline__ int primary_closest(const SceneLds& sc, v3 ro, v3 rd,
     return closest_hit<HAS_NONSPHERE, false, BATCH>(sc, ro, rd, dist, none);
 }
 
+// Large scenes: the hittables some primary ray of the wave hits, found from the clusters some ray of the wave may hit
+// (rt_device.hpp cluster_mask: a skipped cluster holds only tests that certainly return false), in slot order -- the
+// caller sorts the list back into scene order (wavelist_sort) before closest-hit queries walk it.
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ void wave_primary_candidates(const KernelArgs& a, const SceneLds& sc, const float* dirs, v3 origin, bool mine, WaveList& prim)
+{
+    typedef const float __attribute__((address_space(4)))* kptrf;
+    typedef const unsigned int __attribute__((address_space(4)))* kptru;
+    const kptrf kcl = (kptrf)a.clusters;
+    const kptru korder = (kptru)a.order;
+    for (int c = 0; c < a.n_clusters; ++c) {
+        const float4 cb = make_float4(kcl[8 * c + 0], kcl[8 * c + 1], kcl[8 * c + 2], kcl[8 * c + 3]);
+        const float4 ch = make_float4(kcl[8 * c + 4], kcl[8 * c + 5], kcl[8 * c + 6], kcl[8 * c + 7]);
+        bool may = false;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k)
+            may = may || cluster_may_hit(cb, ch, origin, mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]));
+        if (__ballot(may && mine) == 0ull) continue;
+        const int end = 64 * c + 64 < sc.n_hit ? 64 * c + 64 : sc.n_hit;
+        for (int slot = 64 * c; slot < end; ++slot) {
+            const int i = (int)korder[slot];
+            float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
+            bool any = false;
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+                float fa = 4.0f * dot(rd, rd);
+                v3 inv = mk(0, 0, 0);
+                if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                float t;
+                if (!HAS_NONSPHERE) {
+                    f32x4 q = sc.kprim[i];
+                    any = any || sphere_hit_oc(mk(q.x, q.y, q.z), q.w, rd, fa, t);
+                } else {
+                    any = any || hittable_hit<HAS_NONSPHERE>(r0, r1, origin, rd, fa, inv, t);
+                }
+            }
+            wavelist_offer(prim, i, any && mine);
+        }
+    }
+}
+
 // classify_kernel: key[pixel] = 0 when none of the pixel's four primary rays hits a material that bounces
 // (reflection > 0 or refraction > 0, renderer.h:74,93; bounces need depth 1 <= max_depth, renderer.h:68), else
 // 1 + the first such material.  Primary rays are the same for every sample (same u, v; no draw happens before the
 // first hit), so the key holds for the whole pixel.  hist[key] counts pixels per key.
-template <bool HAS_NONSPHERE>
+// BIG (scenes of the cooperative route's size): hittables not staged, queries over the wave's candidate list.
+template <bool HAS_NONSPHERE, bool BIG = false>
 __global__ __launch_bounds__(BLOCK) void classify_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
     __shared__ unsigned int l_hist[RT_MAX_KEYS];
     SceneLds sc;
     float* lds_free;
-    stage_scene(a, lds, sc, lds_free);
+    stage_scene<!BIG>(a, lds, sc, lds_free);
     for (int i = threadIdx.x; i < RT_MAX_KEYS; i += BLOCK) l_hist[i] = 0;
     __syncthreads();
 
     const PixelId p = tiled_pixel(a);
-    if (p.active) {
-        float* dirs = lds_free + threadIdx.x;
+    float* dirs = lds_free + threadIdx.x;
+    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+    WaveList prim;
+    wavelist_init(prim);
+    prim.full = true;                                    // (no list: every query over the scene)
+    if (BIG) {                                           // (whole waves: lanes off the frame come along)
         primary_directions(a, dirs, p.x, p.y);
-        const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+        prim.full = false;
+        wave_primary_candidates<HAS_NONSPHERE>(a, sc, dirs, origin, p.active, prim);
+        if (!prim.full) wavelist_sort(prim);
+    }
+    if (p.active) {
+        if (!BIG) primary_directions(a, dirs, p.x, p.y);
         int key = 0;
 #pragma unroll 1
         for (int k = 0; k < 4 && key == 0; ++k) {
             v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
             float dist;
-            int bi = primary_closest<HAS_NONSPHERE>(sc, origin, rd, dist);
+            int bi = (BIG && !prim.full) ? closest_hit_listed<HAS_NONSPHERE, true>(sc, prim, origin, rd, dist)
+                                         : primary_closest<HAS_NONSPHERE>(sc, origin, rd, dist);
             if (bi >= 0) {
                 int m = rec_material(sc.hrec[2 * bi + 1]);
                 if (sc.mats[10 * m + 4] > 0 || sc.mats[10 * m + 5] > 0) key = m + 1;
@@ -633,36 +686,7 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
             cb = make_float4(kcl[8 * c + 0], kcl[8 * c + 1], kcl[8 * c + 2], kcl[8 * c + 3]);
             ch = make_float4(kcl[8 * c + 4], kcl[8 * c + 5], kcl[8 * c + 6], kcl[8 * c + 7]);
         };
-        for (int c = 0; c < a.n_clusters; ++c) {
-            float4 cb, ch;
-            box(c, cb, ch);
-            bool may = false;
-#pragma unroll 1
-            for (int k = 0; k < 4; ++k)
-                may = may || cluster_may_hit(cb, ch, origin, mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]));
-            if (__ballot(may && mine) == 0ull) continue;
-            const int end = 64 * c + 64 < sc.n_hit ? 64 * c + 64 : sc.n_hit;
-            for (int slot = 64 * c; slot < end; ++slot) {
-                const int i = (int)korder[slot];
-                float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
-                bool any = false;
-#pragma unroll 1
-                for (int k = 0; k < 4; ++k) {
-                    v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
-                    float fa = 4.0f * dot(rd, rd);
-                    v3 inv = mk(0, 0, 0);
-                    if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                    float t;
-                    if (!HAS_NONSPHERE) {
-                        f32x4 q = sc.kprim[i];
-                        any = any || sphere_hit_oc(mk(q.x, q.y, q.z), q.w, rd, fa, t);
-                    } else {
-                        any = any || hittable_hit<HAS_NONSPHERE>(r0, r1, origin, rd, fa, inv, t);
-                    }
-                }
-                wavelist_offer(prim, i, any && mine);
-            }
-        }
+        wave_primary_candidates<HAS_NONSPHERE>(a, sc, dirs, origin, mine, prim);
         if (!prim.full) {
             wavelist_sort(prim);
             WaveBits listed; listed.bits = 0ull;
@@ -1585,7 +1609,10 @@ hipError_t rt_launch_classify(const KernelArgs& a, const LaunchTraits& t, unsign
 {
     const int tiles = a.tiles_x * a.tiles_y;
     const size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
-    hipError_t e = t.nonsphere ? launch_with_lds(classify_kernel<true>, a, tiles, lds, stream)
+    const bool big = RT_DIRECT_CULL && a.n_hit >= RT_DIRECT_BIG && a.clusters && a.order;
+    hipError_t e = big ? (t.nonsphere ? launch_with_lds(classify_kernel<true, true>, a, tiles, rt_launch_lds_bytes(0, a.n_lights, a.n_mat), stream)
+                                      : launch_with_lds(classify_kernel<false, true>, a, tiles, rt_launch_lds_bytes(0, a.n_lights, a.n_mat), stream))
+                 : t.nonsphere ? launch_with_lds(classify_kernel<true>, a, tiles, lds, stream)
                                : launch_with_lds(classify_kernel<false>, a, tiles, lds, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, stream, (const unsigned int*)a.hist, cursor);
