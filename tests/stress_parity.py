@@ -86,6 +86,8 @@ while time.time() < t_end:
     row0 = int(rs.randint(0, H))
     rows = int(rs.randint(1, H - row0 + 1))
     flags = int(rs.choice([0, 0, 0, _abi.RT_FLAG_SINGLE_KERNEL, _abi.RT_FLAG_FORCE_SAMPLE_PARALLEL, _abi.RT_FLAG_FORCE_SOLO]))
+    if rs.randint(3) == 0:
+        flags |= _abi.RT_FLAG_SEQUENCE          # the route of frames in flight (one listed launch, serial pixels sorted by cost)
     want, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, seed, row0=row0, rows=rows, threads=15)
     rt.upload_scene(sc)
     cam = ra.camera35f(sc, W, H)
