@@ -243,10 +243,14 @@ const char* rt_strerror(int status);
  *   rt_debug_rand     : out[i*n_draws + k] = k-th rand() after srand(seeds[i])              (src/rand.h:7,9)
  *   rt_debug_quantise : out[i] = pixel::Set channel value for in[i]                          (src/structs.h:12-17)
  *   rt_debug_intersect: one ray against hittable `index` of the uploaded scene; out = {hit, distance,
- *                       position.xyz, normal.xyz} per ray (rays: n x 6 floats origin, direction) */
+ *                       position.xyz, normal.xyz} per ray (rays: n x 6 floats origin, direction)
+ *   rt_debug_cull     : out[i] = 1 if the large-scene kernels would visit the cluster of hittable `index` for ray i,
+ *                       0 if they would skip it -- which they may only when rt_debug_intersect says "no hit" for
+ *                       every hittable of that cluster (no counterpart in the reference: the skip rule's own test) */
 int rt_debug_rand(rt_ctx* ctx, const uint32_t* seeds, int32_t n_seeds, int32_t n_draws, int32_t* out);
 int rt_debug_quantise(rt_ctx* ctx, const float* in, int32_t n, uint8_t* out);
 int rt_debug_intersect(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays, float* out8);
+int rt_debug_cull(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays, uint8_t* out);
 
 #ifdef __cplusplus
 }

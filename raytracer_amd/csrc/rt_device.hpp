@@ -495,6 +495,10 @@ __device__ __forceinline__ float wave_extreme(float v)
 // the box (rounded outwards, rt_abi.cpp) grown by D / 100: every term of the comparisons is bounded by D |d_i|, the
 // float evaluation is off by less than 9 u of that, 1e-4 of the D |d_i| / 128 the argument needs -- the difference
 // between / 100 and / 128 is there for it.
+// the margin as a fraction of D (the argument above needs >= 1 / 128; tests build with 0 to see that they notice)
+#ifndef RT_CULL_MARGIN
+#define RT_CULL_MARGIN 0.01f
+#endif
 __device__ __forceinline__ bool cluster_may_hit(float4 c, float4 h, v3 ro, v3 rd)
 {
     const float ax = fabsf(rd.x), ay = fabsf(rd.y), az = fabsf(rd.z);
@@ -504,7 +508,7 @@ __device__ __forceinline__ bool cluster_may_hit(float4 c, float4 h, v3 ro, v3 rd
     bool usable = dd >= 1e-6f && dd <= 1e6f && D2 >= 1e-12f && D2 <= 1e24f;
     if (c.w != 0.0f) usable = usable && ax > 1e-12f && ay > 1e-12f && az > 1e-12f;
     if (!usable) return true;
-    const float m = sqrtf(D2) * 0.01f;
+    const float m = sqrtf(D2) * RT_CULL_MARGIN;
     const float Hx = h.x + m, Hy = h.y + m, Hz = h.z + m;
     bool miss = (ox > Hx && rd.x <= 0.0f) || (ox < -Hx && rd.x >= 0.0f)
              || (oy > Hy && rd.y <= 0.0f) || (oy < -Hy && rd.y >= 0.0f)

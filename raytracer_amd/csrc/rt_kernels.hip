@@ -1821,6 +1821,24 @@ hipError_t rt_launch_debug_quantise(const float* in, int n, unsigned char* out, 
     return hipGetLastError();
 }
 
+// out[i] = 1 if the large-scene kernels would visit hittable `index`'s cluster for ray i (rt_device.hpp cluster_mask)
+__global__ void debug_cull_kernel(const float* clusters, const unsigned int* slot_of, int index, const float* rays, int n, unsigned char* out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(slot_of[index] / 64u);
+    const float4 cb = make_float4(clusters[8 * c + 0], clusters[8 * c + 1], clusters[8 * c + 2], clusters[8 * c + 3]);
+    const float4 ch = make_float4(clusters[8 * c + 4], clusters[8 * c + 5], clusters[8 * c + 6], clusters[8 * c + 7]);
+    v3 ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    out[i] = cluster_may_hit(cb, ch, ro, rd) ? 1 : 0;
+}
+
+hipError_t rt_launch_debug_cull(const float* clusters, const unsigned int* slot_of, int index, const float* rays, int n, unsigned char* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(debug_cull_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, clusters, slot_of, index, rays, n, out);
+    return hipGetLastError();
+}
+
 hipError_t rt_launch_debug_intersect(const float4* hrec, int index, const float* rays, int n, float* out8, hipStream_t stream)
 {
     hipLaunchKernelGGL(debug_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, hrec, index, rays, n, out8);

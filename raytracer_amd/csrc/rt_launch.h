@@ -95,6 +95,7 @@ hipError_t rt_launch_tile_pack(const void* rgb, const void* emission, int width,
 hipError_t rt_launch_debug_rand(const unsigned int* seeds, int n_seeds, int n_draws, int* out, hipStream_t stream);
 hipError_t rt_launch_debug_quantise(const float* in, int n, unsigned char* out, hipStream_t stream);
 hipError_t rt_launch_debug_intersect(const float4* hrec, int index, const float* rays, int n, float* out8, hipStream_t stream);
+hipError_t rt_launch_debug_cull(const float* clusters, const unsigned int* slot_of, int index, const float* rays, int n, unsigned char* out, hipStream_t stream);
 // glow post-process (rt_glow.hip)
 hipError_t rt_launch_glow_downsample(const void* src, int srcW, void* dst, int dW, int dH, hipStream_t stream);
 hipError_t rt_launch_glow_blur(const void* src, void* dst, int w, int h, int size, const float* kernel, hipStream_t stream);

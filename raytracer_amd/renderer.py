@@ -205,6 +205,13 @@ class Renderer:
         self._check(self._lib.rt_debug_intersect(self._h, index, rays.ctypes.data, len(rays), out.ctypes.data), "rt_debug_intersect")
         return out
 
+    def debug_cull(self, index, rays):
+        """1 per ray if the large-scene kernels would visit hittable `index`'s cluster, 0 if they would skip it"""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        out = np.zeros(len(rays), dtype=np.uint8)
+        self._check(self._lib.rt_debug_cull(self._h, index, rays.ctypes.data, len(rays), out.ctypes.data), "rt_debug_cull")
+        return out
+
 
 def write_ppm(path, rgb):
     """P6 writer with the reference's header (src/main.cpp:423)."""

@@ -189,6 +189,79 @@ def test_large_scene_culling_edge_cases(rt):
         check(_scaled_about_camera(base, k))
 
 
+def test_cluster_skip_rule_never_skips_a_hit(rt):
+    """The skip rule of the large-scene kernels on its own (rt_debug_cull) against the primitive tests on their own
+    (rt_debug_intersect), for rays aimed to graze: impact parameters within 1e-7 .. 1e-1 of a sphere's radius, lines
+    through a cube's corners, edges and faces offset by as little, origins from inside the hittable to 1e6 sizes away
+    and behind it, directions with zero components and lengths other than 1, hittables from 1e-3 to 1e4 in size and at
+    large coordinates.  A ray the rule would skip must never hit; and the rule must skip most of the rays that miss."""
+    rs = np.random.RandomState(12345)
+    eps = np.array([0.0, 1e-7, 3e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1])
+    back = np.array([-3.0, -1.01, -0.5, 0.0, 0.5, 1.01, 2.0, 10.0, 100.0, 1e4, 1e6])
+
+    def directions(n):
+        d = rs.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        axis = rs.randint(0, 4, size=n)                      # a quarter each: one, two zero components
+        for k in range(n):
+            if axis[k] == 1:
+                d[k, rs.randint(3)] = 0.0
+            elif axis[k] == 2:
+                z = rs.choice(3, 2, replace=False); d[k, z] = 0.0
+            if not d[k].any():
+                d[k, 0] = 1.0
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        return d * rs.choice([1.0, 1.0, 0.5, 3.0, 1e-2, 50.0], size=(n, 1))
+
+    def perpendicular(d):
+        u = np.cross(d, rs.normal(size=d.shape))
+        n = np.linalg.norm(u, axis=1, keepdims=True)
+        u = np.where(n > 0, u / np.where(n > 0, n, 1), 0)
+        return u
+
+    n = 40000
+    skipped_misses = misses = 0
+    cases = [("sphere", (0.0, 0.0, -5.0), 1.0), ("sphere", (3.0, -2.0, 7.0), 1e-3), ("sphere", (0.0, -1000.0, -4.0), 1000.0),
+             ("sphere", (1e5, 2e5, -3e5), 10.0), ("sphere", (0.5, 0.5, 0.5), 1e4),
+             ("cube", (-1.0, 0.0, -6.0), (2.0, 1.0, 0.5)), ("cube", (5.0, 5.0, 5.0), (1e-3, 2e-3, 1e-3)),
+             ("cube", (2.0, 1.5, -6.0), (-1.0, -1.0, -1.0)), ("cube", (-3e4, 1e4, 2e4), (100.0, 300.0, 50.0)),
+             ("cube", (0.0, 0.0, 0.0), (1.0, 0.0, 1.0))]
+    for kind, a, b in cases:
+        sc = scenes.Scene(name="graze")
+        sc.material((0.5, 0.5, 0.5), 0.0, 0.0, 0.0)
+        sc.dirlight((0.0, -1.0, 0.0))
+        d = directions(n)
+        dn = d / np.linalg.norm(d, axis=1, keepdims=True)
+        e = rs.choice(eps, size=n) * rs.choice([-1.0, 1.0], size=n)
+        t0 = rs.choice(back, size=n)
+        if kind == "sphere":
+            sc.sphere(a, b, 0)
+            c, r = np.array(a), float(b)
+            target = c + perpendicular(dn) * (r * (1.0 + e))[:, None]
+            size = r
+        else:
+            sc.cube(a, b, 0)
+            lo, hi = np.minimum(np.array(a), np.array(a) + np.array(b)), np.maximum(np.array(a), np.array(a) + np.array(b))
+            size = float(np.linalg.norm(hi - lo))
+            # a point of the surface: every coordinate at lo, hi or in between (corners, edges, faces), pushed off by e
+            sel = rs.randint(0, 3, size=(n, 3))
+            target = np.where(sel == 0, lo, np.where(sel == 1, hi, lo + rs.uniform(size=(n, 3)) * (hi - lo)))
+            target = target + perpendicular(dn) * (size * e)[:, None]
+        origin = target - dn * (t0 * size)[:, None]
+        rays = np.concatenate([origin, d], axis=1).astype(np.float32)
+        # ... and rays that have nothing to do with the hittable
+        far = np.concatenate([rs.normal(size=(n // 4, 3)) * size * 10 + np.array(a), directions(n // 4)], axis=1).astype(np.float32)
+        rays = np.concatenate([rays, far])
+        rt.upload_scene(sc)
+        hit = rt.debug_intersect(0, rays)[:, 0] != 0
+        may = rt.debug_cull(0, rays) != 0
+        assert not (hit & ~may).any(), (kind, a, b, rays[hit & ~may][:3])
+        misses += int((~hit).sum())
+        skipped_misses += int((~hit & ~may).sum())
+    print("skip rule: %d of %d missing rays skipped" % (skipped_misses, misses))
+    assert skipped_misses > 0.3 * misses
+
+
 def test_large_scene_more_pixels_than_resident_waves(rt):
     """coop_kernel's grid is only as large as fits the GPU at once; its waves take pixels from a queue until the list is
     used up.  A frame with several times more bounce pixels than resident waves (16 384 at most: 4 workgroups of 8
