@@ -571,7 +571,7 @@ __device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd
             if (o < wo) { wo = o; wl = l; }
         }
     }
-    best = tmin;
+    best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), wl));       // (the winner's own: -0 and +0 compare equal)
     return __builtin_amdgcn_readlane(bi, wl);
 }
 
