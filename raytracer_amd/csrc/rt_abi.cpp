@@ -34,6 +34,9 @@
 #ifndef RT_HEAVY_MIN_WORK
 #define RT_HEAVY_MIN_WORK 12000u
 #endif
+#ifndef RT_HEAVY_MIN_WORK_SEQ
+#define RT_HEAVY_MIN_WORK_SEQ 200000u
+#endif
 // draws a pixel with unsteady counts is expected to make in its remaining samples for it to get a wave of its own.
 // 0: the route is off, which is the default -- measured: it shortens the listed kernel but not
 // the frame (glass 1080p alone 171 -> 165 ms at 20000, the wave that renders the longest pixel from its first sample
@@ -695,8 +698,11 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     // the threshold is tuned on DEFAULT-4 (4 hittables, 1 light: 8 primitive tests per query pair);
                     // a bounce costs in proportion to hittables x (1 + lights)
                     const double per_bounce = (double)ctx->n_hit * (1.0 + ctx->n_lights) / 8.0;
-                    double min_work = RT_HEAVY_MIN_WORK / (per_bounce > 1.0 ? per_bounce : 1.0);
-                    g2.heavy_min_work = force ? 0u : (unsigned int)(min_work < 1.0 ? 1.0 : min_work);
+                    /* frames in flight fill the GPU by themselves: there the hand-over only pays for
+                     * the very longest pixels (glass 1080p: 30.7 -> 28.3 ms/frame, 4K headline equal) */
+                    double min_work = (double)((p->flags & RT_FLAG_SEQUENCE) ? RT_HEAVY_MIN_WORK_SEQ : RT_HEAVY_MIN_WORK)
+                                      / (per_bounce > 1.0 ? per_bounce : 1.0);
+                    g2.heavy_min_work = force ? 0u : (unsigned int)(min_work < 1.0 ? 1.0 : min_work > 4.0e9 ? 4.0e9 : min_work);
                     // long pixels whose draw counts differ from sample to sample: a wave each (coop_kernel over solo_list)
                     static const unsigned int solo_work = getenv("RT_SOLO_MIN_WORK") ? (unsigned int)atoll(getenv("RT_SOLO_MIN_WORK")) : RT_SOLO_MIN_WORK;
                     const bool force_solo = (p->flags & RT_FLAG_FORCE_SOLO) != 0;
