@@ -34,8 +34,11 @@
 #ifndef RT_HEAVY_MIN_WORK
 #define RT_HEAVY_MIN_WORK 12000u
 #endif
+// the same bar under RT_FLAG_SEQUENCE; the environment variable of this name overrides it. Measured (DESIGN.md section 5,
+// 3c): 200000 makes glass 1080p 8 % faster with 16 frames in flight and the last frames of a short 4K sequence slower
+// (they run alone, where the hand-over is what shortens them), so it stays equal to RT_HEAVY_MIN_WORK.
 #ifndef RT_HEAVY_MIN_WORK_SEQ
-#define RT_HEAVY_MIN_WORK_SEQ 200000u
+#define RT_HEAVY_MIN_WORK_SEQ RT_HEAVY_MIN_WORK
 #endif
 // draws a pixel with unsteady counts is expected to make in its remaining samples for it to get a wave of its own.
 // 0: the route is off, which is the default -- measured: it shortens the listed kernel but not
@@ -698,9 +701,9 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     // the threshold is tuned on DEFAULT-4 (4 hittables, 1 light: 8 primitive tests per query pair);
                     // a bounce costs in proportion to hittables x (1 + lights)
                     const double per_bounce = (double)ctx->n_hit * (1.0 + ctx->n_lights) / 8.0;
-                    /* frames in flight fill the GPU by themselves: there the hand-over only pays for
-                     * the very longest pixels (glass 1080p: 30.7 -> 28.3 ms/frame, 4K headline equal) */
-                    double min_work = (double)((p->flags & RT_FLAG_SEQUENCE) ? RT_HEAVY_MIN_WORK_SEQ : RT_HEAVY_MIN_WORK)
+                    static const double seq_min_work =
+                        getenv("RT_HEAVY_MIN_WORK_SEQ") ? atof(getenv("RT_HEAVY_MIN_WORK_SEQ")) : (double)RT_HEAVY_MIN_WORK_SEQ;
+                    double min_work = ((p->flags & RT_FLAG_SEQUENCE) && seq_min_work >= 1.0 ? seq_min_work : (double)RT_HEAVY_MIN_WORK)
                                       / (per_bounce > 1.0 ? per_bounce : 1.0);
                     g2.heavy_min_work = force ? 0u : (unsigned int)(min_work < 1.0 ? 1.0 : min_work > 4.0e9 ? 4.0e9 : min_work);
                     // long pixels whose draw counts differ from sample to sample: a wave each (coop_kernel over solo_list)
