@@ -251,7 +251,7 @@ def main():
     import torch.distributed as dist
     import raytracer_amd as ra
     from raytracer_amd import bands
-    from raytracer_amd.pipeline import FramePipeline
+    from raytracer_amd.pipeline import FramePipeline, sleeping_waits
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -283,6 +283,12 @@ def main():
     scene = ra.scenes.BUILTIN[scene_name]()
     seed = 0
     in_flight = max(1, min(_frames_in_flight_arg(sys.argv[1:]), max(args.steps, 1)))
+    # one host thread per frame in flight waits inside rt_render_rows most of the time, polling (HIP's default).
+    # RT_BENCH_WAITS=sleep makes them sleep (raytracer_amd/pipeline.py sleeping_waits: same frame rate, a quarter of the
+    # CPU time); not the default -- a process that mixed the two kinds of wait has hung, see there
+    host_waits = os.environ.get("RT_BENCH_WAITS", "spin") if in_flight > 1 else "spin"
+    if host_waits == "sleep":
+        sleeping_waits(local_rank)
     rts = [ra.Renderer(local_rank) for _ in range(in_flight)]
     for r in rts:
         r.upload_scene(scene)
@@ -464,7 +470,7 @@ def main():
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp": samples, "max_depth": depth,
                        "seed_base": seed, "parallelism": "cyclic %d-row bands over %d GPU(s), gather to rank 0: %s" % (
                            BAND_ROWS, world, "none (one rank)" if world == 1 else "rt_gather_rows (RCCL send/recv group)" if comm else "torch.distributed.gather (%s; %s)" % (backend, gather_mode)),
-                       "frames_in_flight": in_flight, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+                       "frames_in_flight": in_flight, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "host_waits": host_waits},
             "frame_latency_ms": round(float(np.median(latency_ms)), 3),
             "rays": {"primary": tot["primary"], "secondary": tot["closest"] - tot["primary"], "shadow": tot["shadow"],
                      "primitive_tests": tot["tests"], "rng_draws": tot["rand_draws"],
