@@ -283,10 +283,10 @@ def main():
     scene = ra.scenes.BUILTIN[scene_name]()
     seed = 0
     in_flight = max(1, min(_frames_in_flight_arg(sys.argv[1:]), max(args.steps, 1)))
-    # one host thread per frame in flight waits inside rt_render_rows most of the time, polling (HIP's default).
-    # RT_BENCH_WAITS=sleep makes them sleep (raytracer_amd/pipeline.py sleeping_waits: same frame rate, a quarter of the
-    # CPU time); not the default -- a process that mixed the two kinds of wait has hung, see there
-    host_waits = os.environ.get("RT_BENCH_WAITS", "spin") if in_flight > 1 else "spin"
+    # one host thread per frame in flight waits inside rt_render_rows most of the time: under RT_FLAG_SEQUENCE the
+    # library polls an event with short naps there ("nap").  RT_BENCH_WAITS=sleep: HIP's process-wide sleeping waits on
+    # top (raytracer_amd/pipeline.py sleeping_waits; not the default -- a process that mixed the kinds of wait has hung)
+    host_waits = os.environ.get("RT_BENCH_WAITS", "nap") if in_flight > 1 else "spin"
     if host_waits == "sleep":
         sleeping_waits(local_rank)
     rts = [ra.Renderer(local_rank) for _ in range(in_flight)]

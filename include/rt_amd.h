@@ -108,7 +108,7 @@ typedef struct {
                                            each.  Same bytes; the library then favours how many
                                            workgroups are resident over the latency of one frame (the listed kernels
                                            keep their generators in scratch rather than LDS; one launch instead of two
-                                           side by side)                                                             */
+                                           side by side; the calling thread naps between polls while it waits)      */
 
 #define RT_FLAG_RAYS_LISTED            32 /* bounce pixels of small scenes a lane per ray, 16 lanes per pixel, each ray
                                            from a guessed place in the pixel's rand() sequence (rays_kernel): same

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -55,6 +56,8 @@ struct rt_ctx {
     hipStream_t stream2 = nullptr;     // the listed general kernel, beside the direct kernel
     hipStream_t stream3 = nullptr;     // its second launch (RT_MODE_REST) when long pixels are handed over
     hipEvent_t ev_rest = nullptr;
+    hipEvent_t ev_wait = nullptr;           // wait_stream()
+    unsigned long long* h_back = nullptr;   // 8 pinned words: a frame's read-backs (a copy to pageable memory waits inside hipMemcpyAsync, polling)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, ev_list = nullptr, ev_gen = nullptr;
     float last_ms = 0.0f, last_total_ms = 0.0f;
     int last_hip = 0;
@@ -286,6 +289,8 @@ int rt_create(rt_ctx** out, int device_ordinal)
     if (e == hipSuccess) e = hipEventCreate(&ctx->evm);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_list, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gen, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_back, 8 * sizeof(unsigned long long), hipHostMallocDefault);
     // (stream2 / stream3 are created when a frame first needs them: HIP deals streams to its hardware queues as they are
     // created, and callers with many contexts in flight -- RT_FLAG_SEQUENCE -- should not have idle streams pushing
     // busy ones onto shared queues)
@@ -321,6 +326,8 @@ void rt_destroy(rt_ctx* ctx)
     if (ctx->evm) (void)hipEventDestroy(ctx->evm);
     if (ctx->ev_list) (void)hipEventDestroy(ctx->ev_list);
     if (ctx->ev_gen) (void)hipEventDestroy(ctx->ev_gen);
+    if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
+    if (ctx->h_back) (void)hipHostFree(ctx->h_back);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->ev_rest) (void)hipEventDestroy(ctx->ev_rest);
     if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
@@ -569,6 +576,26 @@ int rt_debug_cull(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays,
 // classes live in this GPU's copy of the static scratch array (ctx->scratch), outputs must be device pointers, no
 // tallies, and the sample-parallel route (which needs a stream pool) is left out: long pixels stay with the listed
 // kernel, same bytes.
+// The host waits for the context's stream.  hipStreamSynchronize polls without pause (HIP's default); a caller with frames
+// in flight (RT_FLAG_SEQUENCE) has a host thread per frame, and 16 of them polling kept 12 CPUs busy.  Those callers
+// poll an event with short sleeps in between instead: the wake-up is late by up to the sleep, which the other frames in
+// flight hide (DESIGN.md section 6 has the measurement; HIP's own sleeping waits are a process-wide device flag and
+// not the library's to set).
+#ifndef RT_WAIT_SLEEP_US
+#define RT_WAIT_SLEEP_US 40
+#endif
+static hipError_t wait_stream(rt_ctx* ctx, bool sleep)
+{
+    if (!sleep) return hipStreamSynchronize(ctx->stream);
+    static const long sleep_us = getenv("RT_WAIT_SLEEP_US") ? std::atol(getenv("RT_WAIT_SLEEP_US")) : RT_WAIT_SLEEP_US;
+    if (sleep_us <= 0) return hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipEventRecord(ctx->ev_wait, ctx->stream);
+    if (e != hipSuccess) return e;
+    const timespec nap = { 0, sleep_us * 1000 };
+    while ((e = hipEventQuery(ctx->ev_wait)) == hipErrorNotReady) nanosleep(&nap, nullptr);
+    return e;
+}
+
 static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p,
                             uint8_t* rgb_out, float* emission_out, rt_counters* counters, bool no_alloc)
 {
@@ -650,8 +677,9 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
             HIP_TRY(ctx, hipEventRecord(ctx->ev_list, ctx->stream));
             // the list length sizes the general kernel's grid: scan_kernel leaves it in cursor[0] ... which scatter does
             // not touch (keys are >= 1), so it can be read as soon as the list is complete
-            HIP_TRY(ctx, hipMemcpyAsync(&n_listed, cursor, sizeof(n_listed), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_back[6], cursor, sizeof(n_listed), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, wait_stream(ctx, (p->flags & RT_FLAG_SEQUENCE) != 0));
+            std::memcpy(&n_listed, &ctx->h_back[6], sizeof(n_listed));
             if (n_listed > 0) {
                 KernelArgs g2 = a;
                 g2.list = list; g2.list_count = (int)n_listed;
@@ -785,9 +813,10 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
 
     if (rgb_out && !rgb_dev) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, a.rgb, npix * 3, hipMemcpyDeviceToHost, ctx->stream));
     if (emission_out && !em_dev) HIP_TRY(ctx, hipMemcpyAsync(emission_out, a.emission, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
-    unsigned long long words[6] = { 0, 0, 0, 0, 0, 0 };
-    HIP_TRY(ctx, hipMemcpyAsync(words, state, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long words[6];
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_back, state, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx, (p->flags & RT_FLAG_SEQUENCE) != 0));
+    std::memcpy(words, ctx->h_back, sizeof(words));
     HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_ms, ctx->evm, ctx->ev1));
     HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_total_ms, ctx->ev0, ctx->ev1));
 

@@ -25,16 +25,15 @@ def sleeping_waits(device=0, on=True):
     """Opt-in, for a process that has created no HIP stream yet: host threads that wait for `device` sleep instead of
     spin.  on=False: back to HIP's default (hipDeviceScheduleAuto).
 
-    HIP's default wait polls.  A pipeline with 16 frames in flight has 16 host threads waiting inside
-    rt_render_rows most of the time; polling, they keep 12 CPUs busy (14.0 s of CPU time for 800 frames against
-    3.7 s, same frame rate: tools/r02_cpu_wait.sh), and a host that grants the process 16 CPUs throttles it beyond
-    that (stalls of 40-80 ms, seen in about one run in ten with 20 producers).  The switch is HIP's own,
-    hipSetDeviceFlags(hipDeviceScheduleBlockingSync): per device and process-wide, so the host application's to set,
-    not the library's.  Measured on ROCm 7.2 (tools/exp/wait_cpu.hip): the flag is read when a wait starts, only
-    streams created under it are slept on, hipEventBlockingSync on an event does nothing by itself -- and a process
-    that switched after it had created and destroyed many streams under the default HUNG in hipStreamSynchronize on
-    an idle stream (a GPU test that did so; removed).  Hence not the default anywhere: bench.py takes it with
-    RT_BENCH_WAITS=sleep, tools/pipeline_time.py with RT_WAITS=sleep, both before their first context.  The symbol
+    Not needed for the library's own waits: under RT_FLAG_SEQUENCE rt_render_rows polls an event with short naps
+    (DESIGN.md section 6), which is what keeps 16 producers from occupying 12 CPUs.  This switch is HIP's own,
+    hipSetDeviceFlags(hipDeviceScheduleBlockingSync), and covers every wait of the process (torch's too): per device
+    and process-wide, so the host application's to set, not the library's.  Measured on ROCm 7.2
+    (tools/exp/wait_cpu.hip): the flag is read when a wait starts, only streams created under it are slept on,
+    hipEventBlockingSync on an event does nothing by itself -- and a process that switched after it had created and
+    destroyed many streams under the default HUNG in hipStreamSynchronize on an idle stream (a GPU test that did so;
+    removed).  Hence not the default anywhere: bench.py takes it with RT_BENCH_WAITS=sleep, tools/pipeline_time.py
+    with RT_WAITS=sleep, both before their first context.  The symbol
     is taken through the C-ABI library's handle, i.e. from the HIP runtime that library uses."""
     import ctypes
     from . import _abi
