@@ -34,12 +34,24 @@ for F in [int(f) for f in sys.argv[3:]] or [1]:
     nblocks = F * int(os.environ.get("RT_BLOCKS_PER_WORKER", "2"))
     blocks = [torch.zeros((rpr, W, 3), dtype=torch.uint8, device="cuda") for _ in range(nblocks)]
     torch.cuda.synchronize()
-    pipe = FramePipeline(lambda w, block, k: rts[w].render_rows(cam, p, block), blocks, rpr, 16, rts[0], workers=F)
+    calls = []
+
+    def render(w, block, k):
+        t1 = time.perf_counter()
+        rts[w].render_rows(cam, p, block)
+        calls.append((t1, time.perf_counter(), w, k))
+
+    pipe = FramePipeline(render, blocks, rpr, 16, rts[0], workers=F)
     pipe.run(F)                                         # warm every context
     for rep in range(2):
+        del calls[:]
         t0 = time.perf_counter()
         last = pipe.run(frames)
         dt = time.perf_counter() - t0
+        if os.environ.get("RT_SLOW_CALLS"):         # render calls that took longer than RT_SLOW_CALLS ms: start, duration, worker, frame
+            for a, b, w, k in sorted(calls):
+                if (b - a) * 1e3 > float(os.environ["RT_SLOW_CALLS"]):
+                    print("  slow call: start %.2f ms, %.2f ms long, worker %d, frame %d" % ((a - t0) * 1e3, (b - a) * 1e3, w, k))
         cs = int(last.sum(dtype=torch.int64))
         ref = cs if ref is None else ref
         print("%s ranks %d in-flight %d: %.3f ms/frame over %d frames, checksum %d%s" % (
