@@ -56,6 +56,8 @@ struct rt_ctx {
     hipStream_t stream2 = nullptr;     // the listed general kernel, beside the direct kernel
     hipStream_t stream3 = nullptr;     // its second launch (RT_MODE_REST) when long pixels are handed over
     hipEvent_t ev_rest = nullptr;
+    hipStream_t shared_used = nullptr;      // the shared stream this context's last direct kernel went to (drain_streams)
+    bool counted = false;                   // among g_direct[device].users
     hipEvent_t ev_wait = nullptr;           // wait_stream()
     unsigned long long* h_back = nullptr;   // 8 pinned words: a frame's read-backs (a copy to pageable memory waits inside hipMemcpyAsync, polling)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, ev_list = nullptr, ev_gen = nullptr;
@@ -126,6 +128,20 @@ static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 static std::mutex g_scratch_mutex;
 static unsigned char* g_scratch_ptr[RT_MAX_DEVICES];
 
+// Frames in flight (RT_FLAG_SEQUENCE): the direct kernels of all contexts of a device go round a few streams that the
+// contexts share, instead of each waiting on its context's stream behind that frame's listed kernels.  Contexts that
+// start together (the first frames of a sequence, the last ones) then have their direct kernels running while their
+// listed kernels -- few waves, long chains -- are under way, and the number of busy streams stays near the number of
+// hardware queues (16 contexts + 6 on GPU_MAX_HW_QUEUES=16; a second stream per context measured worse, DESIGN.md
+// section 6).  0 in the environment variable of the same name: off.
+#ifndef RT_SEQ_DIRECT_STREAMS
+#define RT_SEQ_DIRECT_STREAMS 6
+#endif
+#define RT_SEQ_DIRECT_MAX 8
+struct SharedDirect { hipStream_t s[RT_SEQ_DIRECT_MAX] = {}; unsigned turn = 0; int users = 0; };
+static std::mutex g_direct_mutex;
+static SharedDirect g_direct[RT_MAX_DEVICES];
+
 // A failing call leaves the entry point at once; work already queued on the context's streams (kernels, copies into
 // the caller's frame or into locals of the returning function) must not outlive it.
 static void drain_streams(rt_ctx* ctx)
@@ -133,6 +149,7 @@ static void drain_streams(rt_ctx* ctx)
     if (ctx->stream)  (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+    if (ctx->shared_used) (void)hipStreamSynchronize(ctx->shared_used);
 }
 
 // streams a context with RT_FLAG_SEQUENCE works on: 1 (listed kernels in front of the direct kernel) or 2 (beside it)
@@ -283,6 +300,11 @@ int rt_create(rt_ctx** out, int device_ordinal)
     ctx->device = device_ordinal;
     DeviceGuard g(device_ordinal);
     if (!g.ok) { delete ctx; return RT_ERR_NO_DEVICE; }
+    if (device_ordinal < RT_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_direct_mutex);
+        ++g_direct[device_ordinal].users;
+        ctx->counted = true;
+    }
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
@@ -337,6 +359,14 @@ void rt_destroy(rt_ctx* ctx)
     if (ctx->d_gather) (void)hipFree(ctx->d_gather);
     if (ctx->d_glow) (void)hipFree(ctx->d_glow);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->counted) {
+        // the last context of a device takes the shared streams with it (idle: every context waited for its own kernels)
+        std::lock_guard<std::mutex> lock(g_direct_mutex);
+        SharedDirect& sd = g_direct[ctx->device];
+        if (--sd.users == 0)
+            for (hipStream_t& st : sd.s)
+                if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
+    }
     delete ctx;
 }
 
@@ -755,10 +785,11 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     g3.heavy_cap = 0; g3.solo_list = nullptr;
                     return rt_launch_coop(g3, tg, st);
                 };
-                // Frames in flight (RT_FLAG_SEQUENCE): the listed kernels go onto the context's one stream, in front of the
-                // direct kernel -- a frame's own kernels then run one after the other, the kernels of the other frames in
-                // flight beside them.  HIP deals streams to hardware queues as they are created; a context that never needs
-                // a second stream never creates one, so N contexts in flight are N busy queues.
+                // Frames in flight (RT_FLAG_SEQUENCE): the listed kernels go onto the context's one stream (the direct
+                // kernel onto one of the device's shared streams, below; behind the listed kernels on this stream when
+                // those are off) -- the kernels of the other frames in flight run beside them.  HIP deals streams to
+                // hardware queues as they are created; a context that never needs a second stream never creates one, so
+                // N contexts in flight are N busy queues plus the shared ones.
                 static const int seq_streams = getenv("RT_SEQ_STREAMS") ? atoi(getenv("RT_SEQ_STREAMS")) : RT_SEQ_STREAMS_DEFAULT;
                 const bool sequence = g2.heavy_cap > 0 && !coop && !rays && (p->flags & RT_FLAG_SEQUENCE) != 0;
                 hipStream_t s2 = ctx->stream;
@@ -779,6 +810,21 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                 } else if (rays) {
                     HIP_TRY(ctx, rt_launch_rays(g2, tg, s2));
                 } else if (sequence) {
+                    static const int shared_n = std::min(RT_SEQ_DIRECT_MAX, getenv("RT_SEQ_DIRECT_STREAMS") ? atoi(getenv("RT_SEQ_DIRECT_STREAMS")) : RT_SEQ_DIRECT_STREAMS);
+                    if (shared_n > 0 && s2 == ctx->stream && !no_alloc && ctx->counted && n_listed < npix) {
+                        // this frame's direct kernel: onto the next shared stream, behind the classification (ev_list);
+                        // the context's stream waits for it at the end of the frame (ev_gen).  One lock around the
+                        // three calls, so that no other context's kernel gets between this kernel and its event.
+                        std::lock_guard<std::mutex> lock(g_direct_mutex);
+                        SharedDirect& sd = g_direct[ctx->device];
+                        hipStream_t& ds = sd.s[sd.turn++ % (unsigned)shared_n];
+                        if (!ds) HIP_TRY(ctx, hipStreamCreateWithFlags(&ds, hipStreamNonBlocking));
+                        ctx->shared_used = ds;
+                        HIP_TRY(ctx, hipStreamWaitEvent(ds, ctx->ev_list, 0));
+                        HIP_TRY(ctx, rt_launch_direct(a, t, ds));
+                        HIP_TRY(ctx, hipEventRecord(ctx->ev_gen, ds));
+                        direct_done = true; second = true;
+                    }
                     // one launch owns the whole list (one dispatch less per frame; the split below buys latency for a
                     // frame on its own)
                     g2.listed_mode = RT_MODE_ALL;
