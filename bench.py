@@ -283,6 +283,11 @@ def main():
     scene = ra.scenes.BUILTIN[scene_name]()
     seed = 0
     in_flight = max(1, min(_frames_in_flight_arg(sys.argv[1:]), max(args.steps, 1)))
+    if len(scene.hittables) >= 256 and "--frames-in-flight" not in " ".join(sys.argv[1:]):
+        # a large scene's frame fills the GPU by itself (coop_kernel: one wave per bounce pixel from a queue), and its
+        # workgroups want an empty GPU to spread evenly over the SIMDs: frames one at a time
+        # (many2048 1080p/32spp: 0.84 s per frame against 0.92 s with three in flight)
+        in_flight = 1
     # one host thread per frame in flight waits inside rt_render_rows most of the time: under RT_FLAG_SEQUENCE the
     # library polls an event with short naps there ("nap").  RT_BENCH_WAITS=sleep: HIP's process-wide sleeping waits on
     # top (raytracer_amd/pipeline.py sleeping_waits; not the default -- a process that mixed the kinds of wait has hung)
