@@ -574,6 +574,44 @@ def test_frames_in_flight_equal_frames_one_at_a_time(rt):
         assert np.array_equal(got[k], want[k]), "frame %d" % k
 
 
+def test_shared_direct_streams_come_and_go_with_the_contexts():
+    """Under RT_FLAG_SEQUENCE the direct kernels of a device's contexts go round streams the contexts share
+    (rt_abi.cpp, RT_SEQ_DIRECT_STREAMS); the last context of the device destroys them and the next one starts afresh.
+    A process of its own, so that no other context keeps them alive: two contexts render in turn with the flag, are
+    closed, two new ones render again -- always the bytes of a frame rendered without the flag."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import raytracer_amd as ra
+        from raytracer_amd import _abi, bands, scenes
+        sc = scenes.default4()
+        W, H, samples, depth = 192, 96, 8, 6      # (8 samples: the fewest with which the flag changes the route)
+        cam = ra.camera35f(sc, W, H)
+        want = None
+        for generation in range(3):
+            rts = [ra.Renderer(0) for _ in range(2)]
+            for r in rts:
+                r.upload_scene(sc)
+            if want is None:
+                want = [rts[0].render(W, H, samples, depth, seed_base=5 * k)[0] for k in range(4)]
+            for k in range(4):
+                r = rts[k %% 2]
+                p = bands.band_params(r, W, H, samples, depth, 5 * k, 16, 1, 0, flags=_abi.RT_FLAG_SEQUENCE)
+                out = np.zeros((H, W, 3), np.uint8)
+                r.render_rows(cam, p, out)
+                assert np.array_equal(out, want[k]), (generation, k)
+            for r in rts:
+                r.close()
+        print("ok")
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
 def test_gather_rows_over_rccl_single_rank(rt):
     """rt_gather_rows with a real RCCL communicator of one rank: the rank's block goes through ncclSend / ncclRecv (to
     and from itself) into the gather buffer and is reassembled; same bytes as the frame rendered whole.  (More ranks
