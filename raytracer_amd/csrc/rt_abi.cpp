@@ -622,7 +622,11 @@ static hipError_t wait_stream(rt_ctx* ctx, bool sleep)
     hipError_t e = hipEventRecord(ctx->ev_wait, ctx->stream);
     if (e != hipSuccess) return e;
     const timespec nap = { 0, sleep_us * 1000 };
-    while ((e = hipEventQuery(ctx->ev_wait)) == hipErrorNotReady) nanosleep(&nap, nullptr);
+    bool polled = false;
+    while ((e = hipEventQuery(ctx->ev_wait)) == hipErrorNotReady) { polled = true; nanosleep(&nap, nullptr); }
+    // hipErrorNotReady is an answer, not a failure, but HIP keeps it as the thread's last error: take it back, or the
+    // caller's next hipGetLastError() (torch checks it after every kernel launch) reports "device not ready"
+    if (polled && e == hipSuccess) (void)hipGetLastError();
     return e;
 }
 
