@@ -3,7 +3,7 @@
     tools/pipeline_time.py <workload> <frames> <F> [<F> ...]        F = producers (contexts)
 RT_EMULATE_RANKS=N renders rank 0's share of an N-GPU frame (cyclic 16-row bands), i.e. what one rank of an N-GPU
 job does per frame minus the RCCL gather.  RT_HW_QUEUES sets GPU_MAX_HW_QUEUES before HIP starts; RT_FLAGS = rt_params.flags
-(include/rt_amd.h) for A/B runs; RT_WAITS=sleep: sleeping_waits (raytracer_amd/pipeline.py) instead of HIP's polling waits."""
+(include/rt_amd.h) for A/B runs; RT_CHECK_ALL=1 checksums every frame (slower: a check, not a timing); RT_WAITS=sleep: sleeping_waits (raytracer_amd/pipeline.py) instead of HIP's polling waits."""
 import os
 import sys
 import time
@@ -45,9 +45,13 @@ for F in [int(f) for f in sys.argv[3:]] or [1]:
     pipe.run(F)                                         # warm every context
     for rep in range(2):
         del calls[:]
+        sums = []
+        check = (lambda k, f: sums.append(int(f.sum(dtype=torch.int64)))) if os.environ.get("RT_CHECK_ALL") else None
         t0 = time.perf_counter()
-        last = pipe.run(frames)
+        last = pipe.run(frames, on_frame=check)
         dt = time.perf_counter() - t0
+        if check:       # every frame of the run is the same frame: one checksum
+            print("  all %d frames checked: %s" % (len(sums), "one checksum" if len(set(sums)) == 1 else "MISMATCH %s" % sorted(set(sums))[:4]))
         if os.environ.get("RT_SLOW_CALLS"):         # render calls that took longer than RT_SLOW_CALLS ms: start, duration, worker, frame
             for a, b, w, k in sorted(calls):
                 if (b - a) * 1e3 > float(os.environ["RT_SLOW_CALLS"]):
