@@ -246,7 +246,12 @@ const char* rt_strerror(int status);
  *                       position.xyz, normal.xyz} per ray (rays: n x 6 floats origin, direction)
  *   rt_debug_cull     : out[i] = 1 if the large-scene kernels would visit the cluster of hittable `index` for ray i,
  *                       0 if they would skip it -- which they may only when rt_debug_intersect says "no hit" for
- *                       every hittable of that cluster (no counterpart in the reference: the skip rule's own test) */
+ *                       every hittable of that cluster (no counterpart in the reference: the skip rule's own test)
+ *   rt_debug_exact_math: the kernels' short correctly-rounded sqrt, reciprocal and 1/sqrt sequences against the
+ *                       compiler's IEEE sqrtf and division over all 2^32 float bit patterns; mismatches3[k] = inputs on
+ *                       which sequence k differs (0, 0, 0 is the claim; the reference's sqrt / division are IEEE,
+ *                       src/hittables/sphere.h:25-27, glm normalize) */
+int rt_debug_exact_math(rt_ctx* ctx, uint64_t* mismatches3);
 int rt_debug_rand(rt_ctx* ctx, const uint32_t* seeds, int32_t n_seeds, int32_t n_draws, int32_t* out);
 int rt_debug_quantise(rt_ctx* ctx, const float* in, int32_t n, uint8_t* out);
 int rt_debug_intersect(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays, float* out8);

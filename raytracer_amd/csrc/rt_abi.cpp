@@ -1267,6 +1267,22 @@ int rt_debug_rand(rt_ctx* ctx, const uint32_t* seeds, int32_t n_seeds, int32_t n
     return RT_OK;
 }
 
+int rt_debug_exact_math(rt_ctx* ctx, uint64_t* mismatches3)
+{
+    if (!ctx || !mismatches3) return RT_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    unsigned long long* d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_out, 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_out, 0, 3 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = rt_launch_debug_exact_math(d_out, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mismatches3, d_out, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_out);
+    HIP_TRY(ctx, e);
+    return RT_OK;
+}
+
 int rt_debug_quantise(rt_ctx* ctx, const float* in, int32_t n, uint8_t* out)
 {
     if (!ctx || !in || !out || n <= 0) return RT_ERR_INVALID_ARG;

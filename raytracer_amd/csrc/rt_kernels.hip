@@ -38,6 +38,12 @@ constexpr int BLOCK = 256;
 #ifndef RT_DIRECT_BATCH
 #define RT_DIRECT_BATCH 4
 #endif
+// waves per SIMD the sphere-only direct kernel's register allocation must leave room for (80 VGPRs at 6; left alone it
+// takes 85 and runs at 4.7 instead of 5.4 resident waves per SIMD; the variants with planes / cubes or an emission
+// buffer want 100 - 160 and are left alone)
+#ifndef RT_DIRECT_WAVES
+#define RT_DIRECT_WAVES 6
+#endif
 // scenes with at least this many hittables: direct_kernel<.., BIG>
 #ifndef RT_DIRECT_BIG
 #define RT_DIRECT_BIG 256
@@ -75,16 +81,22 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
     // neither write theirs nor use what they read back
     // Where LDS has room for it (sc.xstack: this wave's 2 MAXSP + 3 MAXPEND frames) that copy lives there: a pop then
     // costs an LDS read instead of a trip to the L2.
+    // Where LDS has room for only part of it (large scenes: sc.xstack_n < MAXSP), the first xstack_n colour frames
+    // live there -- paths rarely go deeper -- and the rest, like the emission frames and the pending refraction steps,
+    // in lane 0's scratch, which only lane 0 touches: a pop there is one lane's read, broadcast.
     constexpr bool ONE_COPY = BATCH == RT_COOP;
     const bool keeper = !ONE_COPY || (threadIdx.x & 63) == 0;
     float4* const xs = ONE_COPY ? sc.xstack : nullptr;
+    const int xn = ONE_COPY ? sc.xstack_n : 0;
+    auto in_lds = [&](const float4* arr, int i) { return xs != nullptr && (xn >= MAXSP || (arr == stk && i < xn)); };
     auto put = [&](float4* arr, int i, float4 v) {
-        if (ONE_COPY && xs) { if (keeper) xs[(arr == stk ? 0 : arr == stk_em ? MAXSP : 2 * MAXSP) + i] = v; }
+        if (ONE_COPY && in_lds(arr, i)) { if (keeper) xs[(arr == stk ? 0 : arr == stk_em ? MAXSP : 2 * MAXSP) + i] = v; }
         else if (keeper) arr[i] = v;
     };
     auto get = [&](const float4* arr, int i) -> float4 {
-        if (ONE_COPY && xs) return xs[(arr == stk ? 0 : arr == stk_em ? MAXSP : 2 * MAXSP) + i];       // (every lane reads the one copy)
-        float4 v = arr[i];
+        if (ONE_COPY && in_lds(arr, i)) return xs[(arr == stk ? 0 : arr == stk_em ? MAXSP : 2 * MAXSP) + i];       // (every lane reads the one copy)
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (keeper) v = arr[i];
         if (ONE_COPY) {
             v.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.x)));
             v.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.y)));
@@ -273,7 +285,7 @@ __device__ __forceinline__ void stage_scene(const KernelArgs& a, float4* lds, Sc
     sc.hrec = HREC ? l_hrec : a.hrec; sc.lights = l_lights; sc.mats = l_mats;
     sc.n_hit = a.n_hit; sc.n_lights = a.n_lights;
     sc.khrec = (kptr4)a.hrec; sc.klights = (kptr4)a.lights; sc.kprim = (kptr4)a.prim;
-    sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0; sc.xstack = nullptr;
+    sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0; sc.xstack = nullptr; sc.xstack_n = 0;
     sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
     __syncthreads();
 }
@@ -415,6 +427,26 @@ __device__ __forceinline__ void store_pixel(const KernelArgs& a, size_t o, v3 ac
         a.emission[o] = make_float4(acc_em.x / n, acc_em.y / n, acc_em.z / n, acc_st / n);
 }
 
+// The `pixel` bytes of a wave of the direct kernel (8 x 8 pixels, lane = x + 8 y).  Four neighbours in a row own 12
+// consecutive bytes: where all four lanes are alive (none of the pixels is the listed kernels', which write theirs at
+// their own time, none is off the frame) and the 12 bytes start on a 4-byte boundary, three of the lanes store one dword
+// each -- a row of the block is then two runs of 12 bytes in three stores instead of 24 single bytes.  Otherwise every
+// lane stores its own three bytes.  `mine`: this pixel's first byte.
+__device__ __forceinline__ void store_rgb_quad(unsigned char* mine, unsigned char b0, unsigned char b1, unsigned char b2)
+{
+    const int lane = (int)(threadIdx.x & 63), i = lane & 3;
+    const unsigned int p = (unsigned int)b0 | ((unsigned int)b1 << 8) | ((unsigned int)b2 << 16);
+    const unsigned long long alive = __ballot(true);
+    const bool whole = ((alive >> (lane & 60)) & 0xFull) == 0xFull && ((size_t)(mine - 3 * i) & 3) == 0;
+    // the right-hand neighbour's bytes: quad_perm [1, 2, 3, 3] (read only where the whole quad is alive)
+    const unsigned int q = (unsigned int)__builtin_amdgcn_update_dpp((int)p, (int)p, 0xF9, 0xF, 0xF, false);
+    if (whole) {
+        if (i < 3) *(unsigned int*)(mine + i) = (p >> (8 * i)) | (q << (24 - 8 * i));     // bytes 4 i .. 4 i + 3 of the twelve
+    } else {
+        mine[0] = b0; mine[1] = b1; mine[2] = b2;
+    }
+}
+
 // Hands a long pixel over to heavy_kernel (DESIGN.md "sample-parallel pixels") after its first RT_HEAVY_PROBE
 // samples.  The pixel gets a stretch of the stream pool that starts with the generator's 31 state words in the order
 // they were written (oldest first: the stream continues them, rt_device.hpp RngStreamT), and a record: pixel, the draw
@@ -547,7 +579,7 @@ __device__ __forceinline__ void wave_primary_candidates(const KernelArgs& a, con
                 v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
                 float fa = 4.0f * dot(rd, rd);
                 v3 inv = mk(0, 0, 0);
-                if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                if (HAS_NONSPHERE) inv = mk(rt_rcp(rd.x), rt_rcp(rd.y), rt_rcp(rd.z));
                 float t;
                 if (!HAS_NONSPHERE) {
                     f32x4 q = sc.kprim[i];
@@ -654,7 +686,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(const unsigned short* __
 // candidate lists are built from the clusters some ray of the wave may hit (rt_device.hpp cluster_mask) instead of from
 // the whole scene.
 template <bool EMISSION, bool HAS_NONSPHERE, bool CULL = (RT_DIRECT_CULL != 0), bool BIG = false>
-__global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
+__global__ __launch_bounds__(BLOCK, (HAS_NONSPHERE || EMISSION) ? 1 : RT_DIRECT_WAVES) void direct_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
     SceneLds sc;
@@ -704,7 +736,7 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
                     v3 l = light_direction(sc, j, pos, type, ldist);
                     float fa = 4.0f * dot(l, l);
                     v3 inv = mk(0, 0, 0);
-                    if (HAS_NONSPHERE) inv = mk(1.0f / l.x, 1.0f / l.y, 1.0f / l.z);
+                    if (HAS_NONSPHERE) inv = mk(rt_rcp(l.x), rt_rcp(l.y), rt_rcp(l.z));
                     for (int c = 0; c < a.n_clusters; ++c) {
                         float4 cb, ch;
                         box(c, cb, ch);
@@ -731,7 +763,7 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
                 v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
                 float fa = 4.0f * dot(rd, rd);
                 v3 inv = mk(0, 0, 0);
-                if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                if (HAS_NONSPHERE) inv = mk(rt_rcp(rd.x), rt_rcp(rd.y), rt_rcp(rd.z));
                 float t;
                 if (!HAS_NONSPHERE) {
                     // the same operands as closest_hit_primary (camera-relative terms)
@@ -757,7 +789,7 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
                     v3 l = light_direction(sc, j, pos, type, ldist);
                     float fa = 4.0f * dot(l, l);
                     v3 inv = mk(0, 0, 0);
-                    if (HAS_NONSPHERE) inv = mk(1.0f / l.x, 1.0f / l.y, 1.0f / l.z);
+                    if (HAS_NONSPHERE) inv = mk(rt_rcp(l.x), rt_rcp(l.y), rt_rcp(l.z));
                     for (int i = 0; i < sc.n_hit; ++i) {
                         float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
                         bool o = hit && ((type == L_DIR) ? occluder_hit<HAS_NONSPHERE, false, false>(r0, r1, pos, l, fa, inv, 0.0f)
@@ -835,11 +867,8 @@ __global__ __launch_bounds__(BLOCK) void direct_kernel(KernelArgs a)
     else if (culled) samples(std::integral_constant<int, 1>());
     else        samples(std::integral_constant<int, 0>());
     const float n = (float)a.samples;
-    if (a.rgb) {                                                             // main.cpp:318 -> structs.h:12-17
-        a.rgb[o * 3 + 0] = quantise(acc_color.x / n);
-        a.rgb[o * 3 + 1] = quantise(acc_color.y / n);
-        a.rgb[o * 3 + 2] = quantise(acc_color.z / n);
-    }
+    if (a.rgb)                                                               // main.cpp:318 -> structs.h:12-17
+        store_rgb_quad(a.rgb + o * 3, quantise(acc_color.x / n), quantise(acc_color.y / n), quantise(acc_color.z / n));
     if (EMISSION && a.emission)                                              // main.cpp:319 -> structs.h:39-43
         a.emission[o] = make_float4(acc_em.x / n, acc_em.y / n, acc_em.z / n, acc_st / n);
 }
@@ -1035,7 +1064,10 @@ __global__ __launch_bounds__(COOP_WAVES * 64, RT_COOP_MIN_WAVES) void coop_kerne
     unsigned short* lp = (unsigned short*)(lds_free + (12 + 32) * COOP_WAVES) + wave * (2 * COOP_LIST);
     unsigned short* lo = lp + COOP_LIST;
     // (behind the lists, 16-byte aligned: the waves' bounce stacks, when the launch made room for them)
-    sc.xstack = a.coop_lds_stack ? (float4*)(lds_free + (12 + 32) * COOP_WAVES + COOP_WAVES * COOP_LIST) + (size_t)wave * (2 * MAXSP + 3 * MAXPEND) : nullptr;
+    // (a.coop_lds_stack: colour frames per wave in LDS; MAXSP and more: the whole stack, 2 MAXSP + 3 MAXPEND frames)
+    const int xframes = a.coop_lds_stack >= MAXSP ? 2 * MAXSP + 3 * MAXPEND : a.coop_lds_stack;
+    sc.xstack = a.coop_lds_stack > 0 ? (float4*)(lds_free + (12 + 32) * COOP_WAVES + COOP_WAVES * COOP_LIST) + (size_t)wave * xframes : nullptr;
+    sc.xstack_n = a.coop_lds_stack;
     const unsigned long long below = (1ull << lane) - 1ull;
     const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
     primary_directions<COOP_WAVES>(a, dirs, x, y);
@@ -1056,7 +1088,7 @@ __global__ __launch_bounds__(COOP_WAVES * 64, RT_COOP_MIN_WAVES) void coop_kerne
                 const v3 rd = mk(dirs[(3 * k + 0) * COOP_WAVES], dirs[(3 * k + 1) * COOP_WAVES], dirs[(3 * k + 2) * COOP_WAVES]);
                 const float fa = 4.0f * dot(rd, rd);
                 v3 inv = mk(0, 0, 0);
-                if (HAS_NONSPHERE) inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                if (HAS_NONSPHERE) inv = mk(rt_rcp(rd.x), rt_rcp(rd.y), rt_rcp(rd.z));
                 float t;
                 any = any || hittable_hit<HAS_NONSPHERE, false>(r0, r1, origin, rd, fa, inv, t);
             }
@@ -1094,7 +1126,7 @@ __global__ __launch_bounds__(COOP_WAVES * 64, RT_COOP_MIN_WAVES) void coop_kerne
                 const v3 l = light_direction(sc, j, pos, type, ldist);
                 const float fa = 4.0f * dot(l, l);
                 v3 inv = mk(0, 0, 0);
-                if (HAS_NONSPHERE) inv = mk(1.0f / l.x, 1.0f / l.y, 1.0f / l.z);
+                if (HAS_NONSPHERE) inv = mk(rt_rcp(l.x), rt_rcp(l.y), rt_rcp(l.z));
                 unsigned long long lrounds = cluster_mask(sc, pos, l);
                 while (lrounds != 0ull && fits) {
                     const int i = 64 * __builtin_ctzll(lrounds) + lane;
@@ -1511,6 +1543,25 @@ __global__ __launch_bounds__(BLOCK) void debug_rand_kernel(const unsigned int* s
     for (; k < n_draws; ++k) out[(size_t)i * n_draws + k] = rng.next();
 }
 
+// rt_sqrt / rt_rcp / rt_inv_sqrt (rt_device.hpp) against the compiler's correctly rounded sqrtf and division, over every
+// float bit pattern: out[k] counts the inputs on which sequence k differs (both NaN counts as equal).
+__device__ __forceinline__ bool same_float(float a, float b) { return (a != a && b != b) || __float_as_uint(a) == __float_as_uint(b); }
+
+__global__ __launch_bounds__(BLOCK) void debug_exact_math_kernel(unsigned long long* out)
+{
+    unsigned int bad0 = 0, bad1 = 0, bad2 = 0;
+    const unsigned long long step = (unsigned long long)gridDim.x * BLOCK;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < (1ull << 32); i += step) {
+        const float x = __uint_as_float((unsigned int)i);
+        bad0 += !same_float(rt_sqrt(x), sqrtf(x));
+        bad1 += !same_float(rt_rcp(x), 1.0f / x);
+        bad2 += !same_float(rt_inv_sqrt(x), 1.0f / sqrtf(x));
+    }
+    if (bad0) atomicAdd(&out[0], (unsigned long long)bad0);
+    if (bad1) atomicAdd(&out[1], (unsigned long long)bad1);
+    if (bad2) atomicAdd(&out[2], (unsigned long long)bad2);
+}
+
 __global__ void debug_quantise_kernel(const float* in, int n, unsigned char* out)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1521,11 +1572,11 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0; sc.xstack = nullptr; sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
+    SceneLds sc; sc.hrec = hrec; sc.lights = nullptr; sc.mats = nullptr; sc.n_hit = index + 1; sc.n_lights = 0; sc.khrec = (kptr4)hrec; sc.klights = nullptr; sc.kprim = nullptr; sc.orig = nullptr; sc.slot_of = nullptr; sc.clusters = nullptr; sc.n_clusters = 0; sc.xstack = nullptr; sc.xstack_n = 0; sc.cl_prim = nullptr; sc.cl_nprim = -1; sc.cl_occl = nullptr; sc.cl_noccl = -1;
     v3 ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     float4 r0 = hrec[2 * index], r1 = hrec[2 * index + 1];
     float fa = 4.0f * dot(rd, rd);
-    v3 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    v3 inv = mk(rt_rcp(rd.x), rt_rcp(rd.y), rt_rcp(rd.z));
     float d = -1.0f;
     bool hit = hittable_hit<true>(r0, r1, ro, rd, fa, inv, d);
     float* o = out8 + 8 * i;
@@ -1761,9 +1812,19 @@ hipError_t rt_launch_coop(const KernelArgs& a0, const LaunchTraits& t, hipStream
     size_t lds = coop_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
     // The waves' bounce stacks go into LDS when two workgroups still fit a CU with them, or when the scene is small
     // (the route of long pixels of small scenes: few waves, each a long serial chain of pushes and pops).
+    const int maxsp = t.deep ? RT_STACK_DEEP : RT_STACK_SHALLOW;
     const size_t stack = (size_t)COOP_WAVES * 16 * (t.deep ? 2 * RT_STACK_DEEP + 3 * RT_PEND_DEEP : 2 * RT_STACK_SHALLOW + 3 * RT_PEND_SHALLOW);
-    a.coop_lds_stack = (lds + stack <= 80 * 1024 || (a.n_hit < 256 && lds + stack <= 160 * 1024)) ? 1 : 0;
-    if (a.coop_lds_stack) lds += stack;
+    a.coop_lds_stack = 0;
+    if (lds + stack <= 80 * 1024 || (a.n_hit < 256 && lds + stack <= 160 * 1024)) {
+        a.coop_lds_stack = maxsp;
+        lds += stack;
+    } else if (lds <= 80 * 1024) {
+        // large scenes: as many colour frames per wave as two workgroups per CU leave room for (the scratch copy costs a
+        // 64-byte write per push and four lines per pop: 430 GB of HBM traffic per C4 frame before this)
+        const int frames = (int)((80 * 1024 - lds) / ((size_t)COOP_WAVES * 16));
+        a.coop_lds_stack = frames >= maxsp ? maxsp - 1 : frames >= 4 ? frames : 0;
+        lds += (size_t)COOP_WAVES * 16 * (size_t)a.coop_lds_stack;
+    }
 #define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N)                                \
         return t.deep ? launch_coop(coop_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream)       \
                       : launch_coop(coop_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, stream);
@@ -1812,6 +1873,12 @@ hipError_t rt_launch_tile_pack(const void* rgb, const void* emission, int width,
 hipError_t rt_launch_debug_rand(const unsigned int* seeds, int n_seeds, int n_draws, int* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(debug_rand_kernel, dim3((n_seeds + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, seeds, n_seeds, n_draws, out);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_debug_exact_math(unsigned long long* out3, hipStream_t stream)
+{
+    hipLaunchKernelGGL(debug_exact_math_kernel, dim3(256 * 16), dim3(BLOCK), 0, stream, out3);
     return hipGetLastError();
 }
 

@@ -62,7 +62,8 @@ struct KernelArgs {
     unsigned int* solo_list;     // solo_cap pixels (indices into the packed output)
     unsigned int* solo_count;    // pixels handed over (may run past solo_cap: those were not)
     int solo_cap;
-    int coop_lds_stack;          // coop_kernel: the waves' bounce stacks live in LDS (set by rt_launch_coop)
+    int coop_lds_stack;          // coop_kernel: colour frames of a wave's bounce stack that live in LDS (set by rt_launch_coop;
+                                 // the stack's capacity or more: all of it, emission frames and pending steps included)
     unsigned int solo_min_work;  // hand over when mean draws of the first four samples * (samples left) reaches this
 };
 
@@ -93,6 +94,7 @@ hipError_t rt_launch_deinterleave(const void* gathered, void* frame, int row_byt
 hipError_t rt_launch_tile_pack(const void* rgb, const void* emission, int width, int tile, int tiles_x, int tile_y0, int n_tiles,
                                void* img_rec, void* em_rec, hipStream_t stream);
 hipError_t rt_launch_debug_rand(const unsigned int* seeds, int n_seeds, int n_draws, int* out, hipStream_t stream);
+hipError_t rt_launch_debug_exact_math(unsigned long long* out3, hipStream_t stream);
 hipError_t rt_launch_debug_quantise(const float* in, int n, unsigned char* out, hipStream_t stream);
 hipError_t rt_launch_debug_intersect(const float4* hrec, int index, const float* rays, int n, float* out8, hipStream_t stream);
 hipError_t rt_launch_debug_cull(const float* clusters, const unsigned int* slot_of, int index, const float* rays, int n, unsigned char* out, hipStream_t stream);

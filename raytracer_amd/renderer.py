@@ -205,6 +205,12 @@ class Renderer:
         self._check(self._lib.rt_debug_intersect(self._h, index, rays.ctypes.data, len(rays), out.ctypes.data), "rt_debug_intersect")
         return out
 
+    def debug_exact_math(self):
+        """inputs (of all 2^32 floats) on which the kernels' short sqrt / reciprocal / 1/sqrt differ from IEEE: (0, 0, 0)"""
+        out = np.zeros(3, dtype=np.uint64)
+        self._check(self._lib.rt_debug_exact_math(self._h, out.ctypes.data), "rt_debug_exact_math")
+        return tuple(int(v) for v in out)
+
     def debug_cull(self, index, rays):
         """1 per ray if the large-scene kernels would visit hittable `index`'s cluster, 0 if they would skip it"""
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

@@ -82,6 +82,22 @@ def test_c4_2049_hittables_8_lights_sampled_rows(rt):
     assert np.array_equal(got, want)
 
 
+def test_c4_scene_whole_small_frame_with_tallies(rt):
+    """Every pixel of a small frame of the real C4 scene -- all 33 clusters of the culled large-scene kernels, all 8 point
+    lights -- through the production route (direct_kernel<BIG> + coop_kernel), bytes and emission bits against the
+    oracle; then the tallying build's query counts against the oracle's (hittablesList.h:17-50 semantics)."""
+    sc = scenes.many_objects()
+    W, H, samples, depth, seed = 240, 135, 2, 10, 0
+    rt.upload_scene(sc)
+    rgb, em, _ = rt.render(W, H, samples, depth, seed, emission=True)
+    want, want_em, want_cnt = oracle_lib.render(sc, W, H, samples, depth, seed, threads=THREADS)
+    assert np.array_equal(rgb, want)
+    assert np.array_equal(em.view(np.uint32), want_em.view(np.uint32))
+    _, _, cnt = rt.render(W, H, samples, depth, seed, count=True)
+    for k in ("primary", "closest", "shadow", "tests", "rand_draws"):
+        assert cnt[k] == want_cnt[k], k
+
+
 def test_c5_glass_1080p_64spp_depth12_sampled_rows(rt):
     got, want = sampled_rows(rt, scenes.glass_mirror(), 1920, 1080, 64, 12, 0, 24, row0=7)
     assert np.array_equal(got, want)

@@ -714,6 +714,12 @@ def test_rng_reproduces_glibc(rt, golden_dir):
         assert out[i].tolist() == oracle_lib.rand_sequence(int(seeds[i]), 40)
 
 
+def test_short_sqrt_and_reciprocal_are_ieee_for_every_float(rt):
+    """The kernels' sqrt / 1 / y / 1 / sqrt sequences (rt_device.hpp rt_sqrt, rt_rcp, rt_inv_sqrt) are shorter than the
+    compiler's; the reference's are IEEE (sphere.h:25, glm normalize).  All 2^32 bit patterns, bit for bit."""
+    assert rt.debug_exact_math() == (0, 0, 0)
+
+
 def test_quantise_matches_double_sqrt(rt):
     rs = np.random.RandomState(5)
     vals = [rs.uniform(0, 1, 200000).astype(np.float32), np.linspace(0, 1, 65537, dtype=np.float32)]
