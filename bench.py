@@ -99,14 +99,32 @@ def host_threads():
     return max(1, n - 1)
 
 
+def kernel_source_hash():
+    """sha256 over the sources and build flags the kernels are made of (raytracer_amd/csrc/*.hip|hpp|h|cpp + Makefile, in
+    name order).  tools/pmc_frame.py stores it in profiles/pmc_<workload>.json; a profile whose hash is not this tree's was
+    counted on other kernels, and the roofline object then says so instead of pricing this run with it."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracer_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.h")) +
+                    glob.glob(os.path.join(d, "*.cpp")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def load_pmc(workload):
     """profiles/pmc_<workload>.json (tools/pmc_frame.py over the rocprofv3 --pmc passes of this bench command): executed VALU
-    wave instructions, executed FP32 operations and HBM bytes of one frame.  None when the workload has no profile."""
+    wave instructions, executed FP32 operations and HBM bytes of one frame.  -> (profile, path, stale): no profile: (None,
+    None, False); stale = the profile was taken on other kernel sources than this tree's (kernel_source_hash)."""
     path = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
     if not os.path.exists(path):
-        return None, None
+        return None, None, False
     with open(path) as fh:
-        return json.load(fh), os.path.relpath(path, ROOT)
+        prof = json.load(fh)
+    return prof, os.path.relpath(path, ROOT), prof.get("kernel_source_sha256") != kernel_source_hash()
 
 
 def cpu_baseline(scene, W, H, samples, depth, count_rays, budget_s=20.0):
@@ -139,11 +157,26 @@ def cpu_baseline(scene, W, H, samples, depth, count_rays, budget_s=20.0):
                 step //= 4
             best["value"] = count_rays(best["step"]) / (best["ms"] * 1e-3) / 1e6
             out[kind] = best
+        # the reference's own build line has no -O flag (`g++ -g`, run_cpu.sh:1): the same harness built that way, on a
+        # quarter of the rows
+        ref_o0 = os.path.join(ROOT, "oracle", "_ref", "ref_oracle_O0")
+        if "reference" in out and os.path.exists(ref_o0):
+            step = out["reference"]["step"] * 4
+            r = subprocess.run([ref_o0, "--scene", sp, "--w", str(W), "--h", str(H), "--samples", str(samples), "--depth", str(depth),
+                                "--seed-base", "0", "--threads", str(cores), "--row-step", str(step)], capture_output=True, text=True, check=True)
+            info = json.loads(r.stdout.strip().splitlines()[-1])
+            out["reference_O0"] = {"ms": info["ms"], "step": step, "rows": info["rows"], "value": count_rays(step) / (info["ms"] * 1e-3) / 1e6}
     kind = "reference" if "reference" in out else "port"
     b = out[kind]
     res = {"value": round(b["value"], 3), "unit": "Mrays/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": kind,
+           "flags": "g++ -O2 -std=c++17 -ffp-contract=off -pthread (oracle/Makefile: the reference's headers, unmodified)" if kind == "reference"
+                    else "gcc -O2 -std=c11 -ffp-contract=off (oracle/Makefile)",
            "sample": "every %d-th row (%d rows) of the %dx%d frame at %d spp, %.0f ms, 16x16 tiles on %d worker threads" % (
                b["step"], b["rows"], W, H, samples, b["ms"], cores)}
+    if "reference_O0" in out:
+        o0 = out["reference_O0"]
+        res["reference_own_flags"] = {"flags": "g++ -g -std=c++17 -pthread (the reference's own: run_cpu.sh:1, no -O)", "value": round(o0["value"], 3),
+                                      "sample": "every %d-th row (%d rows), %.0f ms" % (o0["step"], o0["rows"], o0["ms"])}
     if kind == "reference" and "port" in out:
         res["port_value"] = round(out["port"]["value"], 3)
         res["port_sample_ms"] = round(out["port"]["ms"], 1)
@@ -208,7 +241,7 @@ def run_glow(args):
             ms.append((time.perf_counter() - t0) * 1e3)
     t = float(np.mean(ms))
     alg = glow_algorithmic_bytes(W, H, levels)
-    pmc, pmc_path = load_pmc(args.workload)
+    pmc, pmc_path, pmc_stale = load_pmc(args.workload)
     line = {
         "metric": "Mpixels/s through applyGlow (src/main.cpp:163-229) at 4K", "value": round(W * H / (t * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t, 3), "higher_is_better": True, "scaling": "weak",
@@ -216,8 +249,8 @@ def run_glow(args):
         "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp": samples, "levels": int(levels)},
         "verified": verified,
         "roofline": {"bound": "hbm", "achieved": round(alg / (t * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(alg / (t * 1e-3) / 1e9 / 8000.0, 4), "traffic": int(pmc["hbm_bytes"]) if pmc else None,
-                     "algorithmic_bytes": alg, "pmc": pmc_path,
+                     "frac": round(alg / (t * 1e-3) / 1e9 / 8000.0, 4), "traffic": int(pmc["hbm_bytes"]) if pmc and not pmc_stale else None,
+                     "algorithmic_bytes": alg, "pmc": pmc_path, "pmc_stale": bool(pmc_stale),
                      "note": "whole rt_apply_glow call (4 kernels and one 4-byte read-back per level), wall time; algorithmic bytes per "
                              "glow_algorithmic_bytes(); the call is bound by its per-level launch / read-back chain and the blur's "
                              "arithmetic (2.2e9 taps per 4K frame), not by HBM"},
@@ -241,6 +274,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--estimate-tally", action="store_true", help="tally every 32nd row and scale instead of the whole frame (large scenes: the exact tally takes most of a minute)")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed frame with the CPU oracle")
+    ap.add_argument("--no-extras", action="store_true", help="skip the legs after the headline: the relaxed-arithmetic variant of the same workload and the glass 1080p frame")
     ap.add_argument("--flags", type=int, default=0, help="extra rt_params.flags for A/B runs (4 = RT_FLAG_SINGLE_KERNEL, 8 = RT_FLAG_FORCE_SAMPLE_PARALLEL)")
     args = ap.parse_args()
 
@@ -340,6 +374,19 @@ def main():
             kernel_ms.append(rt.last_kernel_ms)
             device_ms.append(rt.last_device_ms)
 
+    def sequence(cam_, p_, blocks_, H_, frames):
+        """`frames` frames of another parameter set through the same contexts, in flight like the headline: -> (seconds
+        per frame, the last frame).  One untimed round first."""
+        def render_(worker, out, k):
+            rts[worker].render_rows(cam_, p_, out)
+        pp = FramePipeline(render_, blocks_, H_, BAND_ROWS, consumer, group=gather_group, workers=in_flight, comm=comm)
+        pp.run(min(in_flight, frames))
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        f_ = pp.run(frames)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t_) / frames, f_
+
     def render_solo(worker, out, k):
         rt_solo.render_rows(cam, p_solo, out)
         kernel_ms.append(rt_solo.last_kernel_ms)
@@ -364,6 +411,7 @@ def main():
     frame = pipe.run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
+    gather_ms = list(pipe.gather_ms)                 # per frame: this rank's gather + reassembly step
     # untimed: the last frame of the timed region against the CPU oracle (the plain-C port, pinned to the reference by
     # tests/test_oracle_golden.py) on every vstep-th row -- the rows the cpu_baseline leg samples
     def progress(what):              # (stderr: the one JSON line stays alone on stdout; a silent run reads as hung)
@@ -371,7 +419,7 @@ def main():
             print("[bench] %s (%.0f s)" % (what, time.perf_counter() - t_start), file=sys.stderr, flush=True)
 
     progress("timed region done: %d frame(s) in %.3f s" % (args.steps, elapsed))
-    verified = None
+    verified, want, vstep = None, None, 16
     if rank == 0 and not args.no_verify:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
@@ -423,14 +471,82 @@ def main():
     local_flops = algorithmic_flops(cnt, scene, W * p.rows, samples)
     # duration of one frame's render kernels when they do not overlap with another frame's
     lf = torch.tensor([local_flops, float(np.mean(kernel_ms))], dtype=torch.float64, device=rdev)
+    kms_min = float(lf[1].item())
     if world > 1:
         dist.all_reduce(tv)
         mx = lf.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        mn = lf.clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
         dist.all_reduce(lf)
-        flops, kms = float(lf[0].item()), float(mx[1].item())
+        flops, kms, kms_min = float(lf[0].item()), float(mx[1].item()), float(mn[1].item())
     else:
         flops, kms = float(lf[0].item()), float(lf[1].item())
     tot = dict(zip(keys, (int(v) for v in tv.tolist())))
+
+    def relaxed_leg():
+        """The same workload with RT_FLAG_RELAXED (include/rt_amd.h): not bit-identical, specified to the north star's
+        tolerance.  Same frames in flight, same ray count (the reference algorithm's); checked against the oracle rows of
+        the verification above with that tolerance."""
+        from raytracer_amd._abi import RT_FLAG_RELAXED
+        p_r = bands.band_params(rt, W, H, samples, depth, seed, BAND_ROWS, world, rank, flags=args.flags | seq | RT_FLAG_RELAXED)
+        sec, f_r = sequence(cam, p_r, blocks, H, args.steps)
+        leg = {"flag": "RT_FLAG_RELAXED", "ms_per_step": round(sec * 1e3, 3), "value": round(tot["closest"] / sec / 1e6, 2), "unit": "Mrays/s",
+               "steps": args.steps, "frames_in_flight": in_flight, "bit_identical": False,
+               "tolerance": ">= 99.9 % of the 8-bit pixels within 1 LSB of the reference's, >= 50 dB PSNR (BASELINE.json north star)"}
+        if want is not None:
+            d = np.abs(f_r[::vstep].cpu().numpy().astype(np.int16) - want.astype(np.int16))
+            per = d.max(axis=-1)
+            mse = float((d.astype(np.float64) ** 2).mean())
+            beyond = int((per > 1).sum())
+            leg["verified"] = {"pixels": int(per.size), "differing_pixels": int((per > 0).sum()), "pixels_beyond_1_lsb": beyond,
+                               "within_1_lsb_frac": round(1.0 - beyond / per.size, 7), "max_delta": int(per.max()),
+                               "psnr_db": None if mse == 0.0 else round(10.0 * float(np.log10(255.0 ** 2 / mse)), 2),
+                               "within_tolerance": beyond <= 0.001 * per.size and (mse == 0.0 or 10.0 * np.log10(255.0 ** 2 / mse) >= 50.0)}
+        pm, pm_path, pm_stale = load_pmc(args.workload + "_relaxed")
+        if pm and not pm_stale:
+            # one frame's kernels one at a time, as for the headline's roofline object
+            rt_solo.render_rows(cam, bands.band_params(rt_solo, W, H, samples, depth, seed, BAND_ROWS, world, rank, flags=args.flags | RT_FLAG_RELAXED), blocks[0])
+            k_ms = rt_solo.last_kernel_ms
+            pf = pm["per_frame"]
+            leg["roofline"] = {"kernel_ms": round(k_ms, 3), "pmc": pm_path,
+                               "valu_issue_frac": round(pf["valu_wave_instructions"] / (k_ms * 1e-3) / 1e9 / (256 * 4 * 2.4 / 2.0), 4),
+                               "timed_region_valu_issue_frac": round(pf["valu_wave_instructions"] / sec / 1e9 / (256 * 4 * 2.4 / 2.0), 4),
+                               "executed_tflops": round(pf["executed_flops"] / (k_ms * 1e-3) / 1e12, 2),
+                               "executed_frac": round(pf["executed_flops"] / (k_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                               "fma_share": round(pf["fma_share_of_fp32_instructions"], 4)}
+        elif pm:
+            leg["roofline"] = {"pmc": pm_path, "pmc_stale": True}
+        return leg
+
+    def glass_leg(name="glass_1080p_64spp", frames=32):
+        """BASELINE.json configs[4] (mirror / glass, 1080p, 64 spp, depth 12) through the same contexts: a driver-timed
+        figure for the workload whose pixels are long.  Exact arithmetic; every 24th row against the oracle."""
+        sname, W2, H2, spp2, depth2 = WORKLOADS[name]
+        sc2 = ra.scenes.BUILTIN[sname]()
+        for r_ in rts + [rt_solo]:
+            r_.upload_scene(sc2)
+        cam2 = ra.camera35f(sc2, W2, H2)
+        rpr2 = bands.rows_per_rank(H2, BAND_ROWS, world)
+        blocks2 = [torch.zeros((rpr2, W2, 3), dtype=torch.uint8, device=dev) for _ in range(len(blocks))]
+        torch.cuda.synchronize()
+        p2 = bands.band_params(rt, W2, H2, spp2, depth2, seed, BAND_ROWS, world, rank, flags=seq)
+        sec, f2 = sequence(cam2, p2, blocks2, H2, frames)
+        t1 = time.perf_counter()
+        rt_solo.render_rows(cam2, bands.band_params(rt_solo, W2, H2, spp2, depth2, seed, BAND_ROWS, world, rank), blocks2[0])
+        alone_ms = (time.perf_counter() - t1) * 1e3
+        cnt2 = rt.render_rows(cam2, bands.band_params(rt, W2, H2, spp2, depth2, seed, BAND_ROWS, world, rank), blocks2[0], count=True)
+        leg = {"workload": name, "config": {"scene": sname, "width": W2, "height": H2, "spp": spp2, "max_depth": depth2},
+               "ms_per_step": round(sec * 1e3, 3), "value": round(cnt2["closest"] / sec / 1e6, 2), "unit": "Mrays/s", "steps": frames,
+               "frames_in_flight": in_flight, "frame_latency_ms": round(alone_ms, 2),
+               "rays": {"primary": cnt2["primary"], "secondary": cnt2["closest"] - cnt2["primary"], "shadow": cnt2["shadow"], "rng_draws": cnt2["rand_draws"]}}
+        if not args.no_verify:
+            step2 = 24
+            n2 = (H2 + step2 - 1) // step2
+            w2 = oracle_lib.render_strided(sc2, W2, H2, spp2, depth2, seed, row0=0, rows=n2, row_step=step2, threads=host_threads())[0]
+            bad2 = int((f2[::step2].cpu().numpy() != w2).any(axis=-1).sum())
+            leg["verified"] = {"rows": n2, "row_step": step2, "pixels": int(n2 * W2), "differing_pixels": bad2, "identical": bad2 == 0}
+        for r_ in rts + [rt_solo]:
+            r_.upload_scene(scene)
+        return leg
 
     if rank == 0:
         rays = tot["closest"]                       # primary + secondary closest-hit queries (renderer.h:40)
@@ -445,10 +561,14 @@ def main():
         # clock) over the kernel time measured here.  Peak issue rate: one wave64 VALU instruction per SIMD per 2 cycles,
         # 1024 SIMDs x 2.4 GHz / 2 -- the rate the 157.3 TFLOP/s figure assumes with every slot an FMA.
         peak_issue = 256 * 4 * 2.4e9 / 2.0 / 1e9                 # G wave instructions / s
-        pmc, pmc_path = load_pmc(args.workload)
+        pmc, pmc_path, pmc_stale = load_pmc(args.workload)
         roof = {"bound": "valu", "achieved": None, "peak": round(peak_issue, 1), "unit": "G wave64 VALU instructions/s", "frac": None,
-                "traffic": None, "kernel_ms": round(kms, 3)}
-        if pmc and world == 1:
+                "traffic": None, "kernel_ms": round(kms, 3), "pmc": pmc_path, "pmc_stale": bool(pmc_stale),
+                "kernel_source_sha256": kernel_source_hash()}
+        if pmc_stale:
+            roof["stale_note"] = ("%s was counted on other kernel sources than this tree's (its hash: %s): frac / achieved / traffic are "
+                                  "left out rather than priced with it; rerun tools/profile_gpu.sh + tools/pmc_frame.py" % (pmc_path, pmc.get("kernel_source_sha256")))
+        if pmc and world == 1 and not pmc_stale:
             pf = pmc["per_frame"]
             issue = pf["valu_wave_instructions"] / (kms * 1e-3) / 1e9
             ex = pf["executed_flops"] / (kms * 1e-3) / 1e12
@@ -468,7 +588,8 @@ def main():
                              "reference algorithm's query tallies: work the kernels partly avoid (candidate lists, shadow pruning), "
                              "not hardware utilisation."})
         line = {
-            "metric": "Mrays/s (primary+secondary) at 4K/64spp; % FP32 VALU peak",
+            "metric": "Mrays/s (primary+secondary) at 4K/64spp; % FP32 VALU peak" + (
+                "" if in_flight == 1 else " [throughput of a sequence of frames, %d in flight]" % in_flight),
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -482,8 +603,20 @@ def main():
                      "note": tally_note},
             "verified": verified,
             "kernel_ms": round(kms, 3), "device_ms_rank0": round(float(np.mean(device_ms)), 3),
+            # where a multi-GPU frame's time goes: RCCL's own count of the communicator's ranks (None: no RCCL communicator
+            # -- one rank, or the torch.distributed fallback), the ranks' kernel spans, rank 0's gather + reassembly step per
+            # frame (device time of rt_gather_rows' RCCL group and rt_deinterleave_bands; wall time on the fallback path)
+            "multi_gpu": {"ranks": world, "rccl_ranks": ra.Renderer.comm_count(comm[0]) if comm else None,
+                          "gather_path": "none (one rank): rt_deinterleave_bands only" if world == 1 else "rt_gather_rows" if comm else "torch.distributed.gather (%s)" % backend,
+                          "kernel_ms_min_over_ranks": round(kms_min, 3), "kernel_ms_max_over_ranks": round(kms, 3),
+                          "gather_ms_rank0": {"mean": round(float(np.mean(gather_ms)), 4), "max": round(float(np.max(gather_ms)), 4)} if gather_ms else None,
+                          "gathered_frame_verified_against_oracle": None if verified is None else verified["identical"]},
             "roofline": roof,
         }
+        if world == 1 and not args.no_extras and args.workload == "default4_4k_64spp" and args.flags == 0:
+            progress("extra legs: relaxed arithmetic, glass 1080p")
+            line["relaxed"] = relaxed_leg()
+            line["secondary"] = [glass_leg()]
         if not args.no_cpu_baseline and world == 1:
             def count_rays(step):
                 n = (H + step - 1) // step
@@ -494,6 +627,12 @@ def main():
         print(json.dumps(line), flush=True)
         if verified is not None and not verified["identical"]:
             raise SystemExit("bench.py: the timed frame differs from the CPU oracle in %d pixels" % verified["differing_pixels"])
+        for leg in [line.get("relaxed")] + (line.get("secondary") or []):
+            v = (leg or {}).get("verified")
+            if v and v.get("identical") is False:
+                raise SystemExit("bench.py: %s differs from the CPU oracle in %d pixels" % (leg["workload"], v["differing_pixels"]))
+            if v and v.get("within_tolerance") is False:
+                raise SystemExit("bench.py: the relaxed-arithmetic frame is outside the north star's tolerance: %r" % (v,))
     if comm:
         consumer.comm_destroy(comm[0])
     consumer.close()

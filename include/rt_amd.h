@@ -117,6 +117,15 @@ typedef struct {
                                            samples for a wave of its own (the route of long pixels whose draw counts
                                            differ from sample to sample)                                             */
 
+#define RT_FLAG_RELAXED               128 /* opt-in: pixels whose primary rays cannot bounce (the direct kernel's, which draw
+                                           no random numbers) are rendered with relaxed float arithmetic -- fused
+                                           multiply-adds, the hardware's 1-ulp sqrt / reciprocal -- instead of the
+                                           reference's operation for operation.  NOT bit-identical: within the tolerance
+                                           the port is specified to (>= 99.9 % of the 8-bit pixels within 1 LSB of the
+                                           reference's, >= 50 dB); tests/test_gpu_relaxed.py has the measured margins.
+                                           Bounce pixels and every other flag keep the exact arithmetic.  Ignored by the
+                                           tallying builds and RT_FLAG_SINGLE_KERNEL (they run the exact general kernel)  */
+
 /* Query tallies with the reference's meaning: primary = W*rows*samples*4; closest = TraceRay closest-hit queries
  * (src/renderer.h:40); shadow = hasIntersect / point-light occlusion queries (directionalLight.h:13); tests =
  * primitive intersect() calls; rand_draws = RANDOM_UNIT calls; shaded = closest-hit queries that hit (one
@@ -195,6 +204,11 @@ int  rt_gather_rows(rt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t nranks, 
                     void* frame_on_rank0, int32_t width, int32_t height, int32_t bytes_per_pixel, int32_t band_rows,
                     int32_t rows_per_rank);
 int  rt_last_rccl_error(const rt_ctx* ctx);          /* ncclResult_t of the last failing RCCL call of the context */
+/* Observability of a multi-GPU run (the reference prints its recompose time, src/main.cpp:369-397): the number of ranks
+ * the communicator spans as RCCL sees it (ncclCommCount), and the device time of the context's last rt_gather_rows -- its
+ * RCCL group and the reassembly on rank 0, from HIP events on the context's stream. */
+int   rt_comm_count(void* nccl_comm, int32_t* nranks_out);
+float rt_last_gather_ms(const rt_ctx* ctx);
 
 /* One frame over the ranks of a job, for hosts that hold no device memory of their own (the C++ host of
  * raytracer_amd/host): renders this rank's cyclic band_rows-row bands of the params->width x params->height frame

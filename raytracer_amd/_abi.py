@@ -18,12 +18,13 @@ RT_FLAG_FORCE_SAMPLE_PARALLEL = 8
 RT_FLAG_SEQUENCE = 16
 RT_FLAG_RAYS_LISTED = 32
 RT_FLAG_FORCE_SOLO = 64
+RT_FLAG_RELAXED = 128
 RT_COMM_ID_BYTES = 128
 RT_ERR_RCCL = -9
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_render_rows_static", "rt_render_tiles", "rt_probe_max_depth",
-    "rt_deinterleave_bands", "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy", "rt_gather_rows", "rt_render_gather", "rt_last_rccl_error", "rt_apply_glow",
+    "rt_deinterleave_bands", "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy", "rt_gather_rows", "rt_render_gather", "rt_last_rccl_error", "rt_comm_count", "rt_last_gather_ms", "rt_apply_glow",
     "rt_last_kernel_ms", "rt_last_device_ms", "rt_last_hip_error", "rt_strerror",
     "rt_debug_rand", "rt_debug_quantise", "rt_debug_intersect", "rt_debug_cull", "rt_debug_exact_math",
 ]
@@ -94,6 +95,9 @@ def load():
     lib.rt_comm_destroy.restype = None
     lib.rt_gather_rows.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32]
     lib.rt_last_rccl_error.argtypes = [vp]
+    lib.rt_comm_count.argtypes = [vp, ctypes.POINTER(i32)]
+    lib.rt_last_gather_ms.argtypes = [vp]
+    lib.rt_last_gather_ms.restype = ctypes.c_float
     lib.rt_apply_glow.argtypes = [vp, vp, vp, i32, i32, ctypes.POINTER(i32)]
     lib.rt_render_gather.argtypes = [vp, ctypes.POINTER(Camera35f), ctypes.POINTER(Params), vp, i32, i32, i32, vp]
     lib.rt_last_kernel_ms.argtypes = [vp]

@@ -61,7 +61,8 @@ struct rt_ctx {
     hipEvent_t ev_wait = nullptr;           // wait_stream()
     unsigned long long* h_back = nullptr;   // 8 pinned words: a frame's read-backs (a copy to pageable memory waits inside hipMemcpyAsync, polling)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, ev_list = nullptr, ev_gen = nullptr;
-    float last_ms = 0.0f, last_total_ms = 0.0f;
+    float last_ms = 0.0f, last_total_ms = 0.0f, last_gather_ms = 0.0f;
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;   // rt_gather_rows: around the RCCL group and the reassembly
     int last_hip = 0;
     int last_rccl = 0;
 
@@ -312,6 +313,8 @@ int rt_create(rt_ctx** out, int device_ordinal)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_list, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gen, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_g0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_g1);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_back, 8 * sizeof(unsigned long long), hipHostMallocDefault);
     // (stream2 / stream3 are created when a frame first needs them: HIP deals streams to its hardware queues as they are
     // created, and callers with many contexts in flight -- RT_FLAG_SEQUENCE -- should not have idle streams pushing
@@ -349,6 +352,8 @@ void rt_destroy(rt_ctx* ctx)
     if (ctx->ev_list) (void)hipEventDestroy(ctx->ev_list);
     if (ctx->ev_gen) (void)hipEventDestroy(ctx->ev_gen);
     if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
+    if (ctx->ev_g0) (void)hipEventDestroy(ctx->ev_g0);
+    if (ctx->ev_g1) (void)hipEventDestroy(ctx->ev_g1);
     if (ctx->h_back) (void)hipHostFree(ctx->h_back);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->ev_rest) (void)hipEventDestroy(ctx->ev_rest);
@@ -373,6 +378,7 @@ void rt_destroy(rt_ctx* ctx)
 int rt_last_hip_error(const rt_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
 float rt_last_kernel_ms(const rt_ctx* ctx) { return ctx ? ctx->last_ms : 0.0f; }
 float rt_last_device_ms(const rt_ctx* ctx) { return ctx ? ctx->last_total_ms : 0.0f; }
+float rt_last_gather_ms(const rt_ctx* ctx) { return ctx ? ctx->last_gather_ms : 0.0f; }
 
 int rt_camera_init(rt_camera35f* cam, float fov_deg, float width, float height, float z_near, float z_far)
 {
@@ -691,6 +697,11 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
         // one closest-hit query per primary direction -- go, grouped by material, to the general kernel on a second
         // stream; all other pixels need no RNG, stack or scratch and go to the direct kernel.
         const bool bounces = ctx->any_bounce && p->max_depth >= 1;       // renderer.h:68: depth 1 <= maxTotalDepth
+        // RT_FLAG_RELAXED: the direct kernel of rt_kernels_relaxed.hip (fused multiply-adds, 1-ulp sqrt / reciprocal)
+        const bool relaxed = (p->flags & RT_FLAG_RELAXED) != 0;
+        auto launch_direct = [relaxed](const KernelArgs& ka, const LaunchTraits& lt, hipStream_t st) {
+            return relaxed ? rt_launch_direct_relaxed(ka, lt, st) : rt_launch_direct(ka, lt, st);
+        };
         unsigned int n_listed = 0;
         bool rest = false, second = false, timed = false, direct_done = false;
         if (bounces) {
@@ -809,7 +820,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                 }
                 if (s2 == ctx->stream) { HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream)); timed = true; }   // the kernel span starts here
                 if (coop) {
-                    if (n_listed < npix) { HIP_TRY(ctx, rt_launch_direct(a, t, ctx->stream)); direct_done = true; }
+                    if (n_listed < npix) { HIP_TRY(ctx, launch_direct(a, t, ctx->stream)); direct_done = true; }
                     HIP_TRY(ctx, rt_launch_coop(g2, tg, s2));
                 } else if (rays) {
                     HIP_TRY(ctx, rt_launch_rays(g2, tg, s2));
@@ -825,7 +836,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                         if (!ds) HIP_TRY(ctx, hipStreamCreateWithFlags(&ds, hipStreamNonBlocking));
                         ctx->shared_used = ds;
                         HIP_TRY(ctx, hipStreamWaitEvent(ds, ctx->ev_list, 0));
-                        HIP_TRY(ctx, rt_launch_direct(a, t, ds));
+                        HIP_TRY(ctx, launch_direct(a, t, ds));
                         HIP_TRY(ctx, hipEventRecord(ctx->ev_gen, ds));
                         direct_done = true; second = true;
                     }
@@ -855,7 +866,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
             }
         }
         if (!timed) HIP_TRY(ctx, hipEventRecord(ctx->evm, ctx->stream));
-        if (n_listed < npix && !direct_done) HIP_TRY(ctx, rt_launch_direct(a, t, ctx->stream));
+        if (n_listed < npix && !direct_done) HIP_TRY(ctx, launch_direct(a, t, ctx->stream));
         if (second) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gen, 0));
         if (rest) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_rest, 0));
     }
@@ -1005,6 +1016,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -1030,6 +1042,7 @@ const Rccl& rccl()
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
         r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
         r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
@@ -1083,6 +1096,17 @@ void rt_comm_destroy(void* comm)
     if (comm && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)comm);
 }
 
+int rt_comm_count(void* comm, int32_t* nranks_out)
+{
+    if (!comm || !nranks_out) return RT_ERR_INVALID_ARG;
+    const Rccl& r = rccl();
+    if (!r.ok || !r.CommCount) return RT_ERR_RCCL;
+    int n = 0;
+    if (r.CommCount((ncclComm_t)comm, &n) != ncclSuccess) return RT_ERR_RCCL;
+    *nranks_out = n;
+    return RT_OK;
+}
+
 int rt_last_rccl_error(const rt_ctx* ctx) { return ctx ? ctx->last_rccl : 0; }
 
 int rt_gather_rows(rt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t nranks, const void* my_block, void* gathered_on_rank0,
@@ -1101,6 +1125,7 @@ int rt_gather_rows(rt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t nranks, c
     if (!g.ok) return RT_ERR_NO_DEVICE;
     const size_t block_bytes = (size_t)rows_per_rank * width * bytes_per_pixel;
     const void* blocks = my_block;                    // one rank without a communicator: its block is the gather buffer
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_g0, ctx->stream));
     if (nccl_comm) {
         // every rank sends its block to rank 0, which receives one block per rank (its own too): one group, so the
         // transfers of all peers run side by side, one xGMI link each
@@ -1119,7 +1144,9 @@ int rt_gather_rows(rt_ctx* ctx, void* nccl_comm, int32_t rank, int32_t nranks, c
     }
     if (rank == 0 && frame_on_rank0)
         HIP_TRY(ctx, rt_launch_deinterleave(blocks, frame_on_rank0, width * bytes_per_pixel, height, band_rows, nranks, rows_per_rank, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_g1, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the block may be rendered into again, the frame read
+    HIP_TRY(ctx, hipEventElapsedTime(&ctx->last_gather_ms, ctx->ev_g0, ctx->ev_g1));
     return RT_OK;
 }
 

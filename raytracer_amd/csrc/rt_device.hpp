@@ -11,7 +11,10 @@
 #define RT_UNROLL 1
 #endif
 
-namespace rt {
+#ifndef RT_NS
+#define RT_NS rt
+#endif
+namespace RT_NS {
 
 struct v3 { float x, y, z; };
 
@@ -32,6 +35,12 @@ __device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y
 //   inf and NaN come out right by themselves; inputs below 2^-104 would lose the residual's sign to underflow).
 //   rt_rcp: one Newton step on v_rcp_f32 (1 ulp) with fused residuals rounds correctly whenever y and 1 / y are both
 //   normal numbers.
+// RT_RELAXED (rt_kernels_relaxed.hip, the direct kernel behind RT_FLAG_RELAXED): not the reference's bits but within
+// the north star's tolerance -- the hardware's 1-ulp square root, reciprocal and reciprocal square root as they are, and
+// the translation unit is built with fused multiply-adds allowed.
+#ifndef RT_RELAXED
+#define RT_RELAXED 0
+#endif
 #ifndef RT_SHORT_EXACT
 #define RT_SHORT_EXACT 1
 #endif
@@ -40,7 +49,9 @@ __device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y
 #define RT_ANY_LANE(c) (c)
 __device__ __forceinline__ float rt_sqrt(float x)
 {
-#if RT_SHORT_EXACT
+#if RT_RELAXED
+    return __builtin_amdgcn_sqrtf(x);
+#elif RT_SHORT_EXACT
     if (__builtin_expect(RT_ANY_LANE(x < 0x1p-96f), 0)) return sqrtf(x); // tiny, zero, negative
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
@@ -54,7 +65,9 @@ __device__ __forceinline__ float rt_sqrt(float x)
 }
 __device__ __forceinline__ float rt_rcp(float y)
 {
-#if RT_SHORT_EXACT
+#if RT_RELAXED
+    return __builtin_amdgcn_rcpf(y);
+#elif RT_SHORT_EXACT
     const float a = fabsf(y);
     if (__builtin_expect(RT_ANY_LANE(!(a >= 0x1p-126f && a <= 0x1p126f)), 0)) return 1.0f / y;   // zero, denormal, huge, inf, NaN
     const float r = __builtin_amdgcn_rcpf(y);
@@ -67,7 +80,9 @@ __device__ __forceinline__ float rt_rcp(float y)
 // rt_rcp's fast path holds, so one range test serves both
 __device__ __forceinline__ float rt_inv_sqrt(float x)
 {
-#if RT_SHORT_EXACT
+#if RT_RELAXED
+    return __builtin_amdgcn_rsqf(x);
+#elif RT_SHORT_EXACT
     if (__builtin_expect(RT_ANY_LANE(!(x >= 0x1p-96f && x <= 3.402823466e+38f)), 0)) return 1.0f / sqrtf(x);
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
@@ -85,9 +100,23 @@ __device__ __forceinline__ v3 normalize(v3 a) { return a * rt_inv_sqrt(dot(a, a)
 // glm reflect = I - N * dot(N,I) * 2 (func_geometric.inl:108)
 __device__ __forceinline__ v3 reflect(v3 I, v3 N) { return I - (N * dot(N, I)) * 2.0f; }
 // glm min/max (func_common.inl:20,29): NaN handling follows the comparisons, so no fminf/fmaxf here
+#if RT_RELAXED
+__device__ __forceinline__ float gmin(float x, float y) { return fminf(x, y); }      // (one instruction; differs for NaNs only)
+__device__ __forceinline__ float gmax(float x, float y) { return fmaxf(x, y); }
+#else
 __device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
 __device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }
+#endif
 __device__ __forceinline__ float clamp01(float x) { return gmin(gmax(x, 0.0f), 1.0f); }
+
+// coop_kernel: all 64 lanes of a wave hold one pixel's path, so its state is the same in every lane.  Passing a value
+// through v_readfirstlane tells the compiler so, and it keeps the value in a scalar register: the path state (some 50
+// values) then costs no vector registers, which the kernel's occupancy hangs on.  ON = false: the value as it is.
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned int uni(unsigned int v) { return (unsigned int)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ v3 uni(v3 v) { return mk(uni(v.x), uni(v.y), uni(v.z)); }
+template <bool ON, class T> __device__ __forceinline__ void make_uniform(T& v) { if (ON) v = uni(v); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Scene image.  The host flattens the scene into these records (rt_abi.cpp), the kernel stages them into LDS once
@@ -1165,4 +1194,4 @@ __device__ __forceinline__ unsigned char quantise(float c)
     return (unsigned char)(int)d;
 }
 
-}  // namespace rt
+}  // namespace RT_NS

@@ -18,7 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-namespace rt {
+namespace RT_NS {
 
 constexpr int BLOCK = 256;
 // waves per SIMD the register allocator must leave room for in the tiled general kernel (72 VGPRs at 7)
@@ -50,6 +50,12 @@ constexpr int BLOCK = 256;
 #endif
 #ifndef RT_LISTED_WAVES
 #define RT_LISTED_WAVES 4
+#endif
+// coop_kernel: the path state in scalar registers (rt_device.hpp uni()).  Off: measured on C4
+// it takes the register spills from 43 to 16 and the kernel's HBM traffic from 194 to 94 GB per frame, at 3 % more
+// instructions and 846 instead of 833 ms -- the spills are not what the frame waits for.
+#ifndef RT_COOP_UNIFORM
+#define RT_COOP_UNIFORM 0
 #endif
 // how many of the first four samples must have drawn the same count for a pixel to be handed over (measured: with 3
 // or 2, C5 gets slower -- 186 / 210 instead of 175 ms -- and nothing gets faster)
@@ -119,6 +125,12 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
 
     for (;;) {
         bool need_refr = false;
+#if RT_COOP_UNIFORM
+        if (ONE_COPY) {                                  // (rt_device.hpp uni(): the path state into scalar registers)
+            make_uniform<ONE_COPY>(ro); make_uniform<ONE_COPY>(rd); make_uniform<ONE_COPY>(mult); make_uniform<ONE_COPY>(depth);
+            make_uniform<ONE_COPY>(maxDepth); make_uniform<ONE_COPY>(sp); make_uniform<ONE_COPY>(pp);
+        }
+#endif
 
         // ---- TraceRay entry for (ro, rd, mult, depth)
         if (mult < 0.001f) {                                                     // renderer.h:30-34
@@ -188,6 +200,14 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
         // ---- refraction step of the current node, or return to the parent(s)
         bool resumed = false;
         for (;;) {
+#if RT_COOP_UNIFORM
+            if (ONE_COPY) {
+                make_uniform<ONE_COPY>(color); make_uniform<ONE_COPY>(mat); make_uniform<ONE_COPY>(sp); make_uniform<ONE_COPY>(pp);
+                make_uniform<ONE_COPY>(hpos); make_uniform<ONE_COPY>(hnorm); make_uniform<ONE_COPY>(inDir);
+                make_uniform<ONE_COPY>(mult); make_uniform<ONE_COPY>(depth); make_uniform<ONE_COPY>(maxDepth);
+                if (EMISSION) { make_uniform<ONE_COPY>(emission); make_uniform<ONE_COPY>(strength); }
+            }
+#endif
             if (need_refr) {
                 need_refr = false;
                 const float* m = sc.mats + 10 * mat;
@@ -400,6 +420,10 @@ __device__ __forceinline__ SampleOut render_sample(const KernelArgs& a, const Sc
             res_em = res_em + p.emission;
             res_st = (k == 0) ? p.strength : gmax(res_st, p.strength);
         }
+#if RT_COOP_UNIFORM
+        make_uniform<BATCH == RT_COOP>(res_color);
+        if (EMISSION) { make_uniform<BATCH == RT_COOP>(res_em); make_uniform<BATCH == RT_COOP>(res_st); }
+#endif
     }
     SampleOut o;
     res_color = res_color * 0.25f;
@@ -512,6 +536,11 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
         SampleOut so = render_sample<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, RNG, BATCH, STRIDE>(a, sc, rng, dirs, origin, cnt);
         acc_color = acc_color + so.color;
         if (EMISSION) { acc_em = acc_em + so.emission; acc_st += so.strength; }
+#if RT_COOP_UNIFORM
+        make_uniform<BATCH == RT_COOP>(acc_color);
+        if (EMISSION) { make_uniform<BATCH == RT_COOP>(acc_em); make_uniform<BATCH == RT_COOP>(acc_st); }
+        make_uniform<BATCH == RT_COOP>(rng.f); make_uniform<BATCH == RT_COOP>(rng.ndraws);
+#endif
         if (HEAVY && a.heavy_cap > 0 && s < RT_HEAVY_PROBE) {
             // The first four samples tell whether the pixel's draw count repeats (a path whose shape does not hang on
             // the numbers drawn, mostly): at least RT_HEAVY_AGREE of them drew the same count, which becomes the guess.
@@ -1590,10 +1619,10 @@ __global__ void debug_intersect_kernel(const float4* hrec, int index, const floa
     }
 }
 
-}  // namespace rt
+}  // namespace RT_NS
 
 // ---- launchers ------------------------------------------------------------------------------------------------
-using namespace rt;
+using namespace RT_NS;
 
 // kernel variants by (emission buffer, reflect-and-refract material, planes or cubes).  RT_DEV_FAST (experiments only):
 // just the three that the bench workloads use, for a quick build.
@@ -1616,6 +1645,28 @@ static hipError_t launch_with_lds(K k, const KernelArgs& a, int blocks, size_t l
     return hipGetLastError();
 }
 
+// The direct kernel's launcher.  This file is compiled twice: as it is, and through rt_kernels_relaxed.hip with relaxed
+// float arithmetic (RT_RELAXED_TU), where it yields the direct kernel and this launcher under another name and nothing else.
+#ifdef RT_RELAXED_TU
+#define RT_LAUNCH_DIRECT rt_launch_direct_relaxed
+#else
+#define RT_LAUNCH_DIRECT rt_launch_direct
+#endif
+hipError_t RT_LAUNCH_DIRECT(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
+{
+    const int tiles = a.tiles_x * a.tiles_y;
+    if (RT_DIRECT_CULL && a.n_hit >= RT_DIRECT_BIG && a.clusters && a.order) {
+        // large scenes: no hittables in LDS, candidate lists from the clusters
+        const size_t lds = rt_launch_lds_bytes(0, a.n_lights, a.n_mat);
+        if (t.emission) return t.nonsphere ? launch_with_lds(direct_kernel<true, true, true, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<true, false, true, true>, a, tiles, lds, stream);
+        return t.nonsphere ? launch_with_lds(direct_kernel<false, true, true, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<false, false, true, true>, a, tiles, lds, stream);
+    }
+    const size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+    if (t.emission) return t.nonsphere ? launch_with_lds(direct_kernel<true, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<true, false>, a, tiles, lds, stream);
+    return t.nonsphere ? launch_with_lds(direct_kernel<false, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<false, false>, a, tiles, lds, stream);
+}
+
+#ifndef RT_RELAXED_TU
 size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat)
 {
     size_t nm = (size_t)((10 * n_mat + 3) & ~3);
@@ -1672,20 +1723,6 @@ hipError_t rt_launch_classify(const KernelArgs& a, const LaunchTraits& t, unsign
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(BLOCK), 0, stream, (const unsigned short*)a.keys, n, cursor, list);
     return hipGetLastError();
-}
-
-hipError_t rt_launch_direct(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
-{
-    const int tiles = a.tiles_x * a.tiles_y;
-    if (RT_DIRECT_CULL && a.n_hit >= RT_DIRECT_BIG && a.clusters && a.order) {
-        // large scenes: no hittables in LDS, candidate lists from the clusters
-        const size_t lds = rt_launch_lds_bytes(0, a.n_lights, a.n_mat);
-        if (t.emission) return t.nonsphere ? launch_with_lds(direct_kernel<true, true, true, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<true, false, true, true>, a, tiles, lds, stream);
-        return t.nonsphere ? launch_with_lds(direct_kernel<false, true, true, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<false, false, true, true>, a, tiles, lds, stream);
-    }
-    const size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
-    if (t.emission) return t.nonsphere ? launch_with_lds(direct_kernel<true, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<true, false>, a, tiles, lds, stream);
-    return t.nonsphere ? launch_with_lds(direct_kernel<false, true>, a, tiles, lds, stream) : launch_with_lds(direct_kernel<false, false>, a, tiles, lds, stream);
 }
 
 bool rt_launch_heavy_fits(int n_hit, int n_lights, int n_mat)
@@ -1815,13 +1852,16 @@ hipError_t rt_launch_coop(const KernelArgs& a0, const LaunchTraits& t, hipStream
     const int maxsp = t.deep ? RT_STACK_DEEP : RT_STACK_SHALLOW;
     const size_t stack = (size_t)COOP_WAVES * 16 * (t.deep ? 2 * RT_STACK_DEEP + 3 * RT_PEND_DEEP : 2 * RT_STACK_SHALLOW + 3 * RT_PEND_SHALLOW);
     a.coop_lds_stack = 0;
-    if (lds + stack <= 80 * 1024 || (a.n_hit < 256 && lds + stack <= 160 * 1024)) {
+    // workgroups the register bound lets a CU hold, and the LDS each may take without lowering that
+    constexpr int per_cu = (4 * RT_COOP_MIN_WAVES) / COOP_WAVES > 0 ? (4 * RT_COOP_MIN_WAVES) / COOP_WAVES : 1;
+    const size_t share = (size_t)160 * 1024 / per_cu;
+    if (lds + stack <= share || (a.n_hit < 256 && lds + stack <= 160 * 1024)) {
         a.coop_lds_stack = maxsp;
         lds += stack;
-    } else if (lds <= 80 * 1024) {
-        // large scenes: as many colour frames per wave as two workgroups per CU leave room for (the scratch copy costs a
+    } else if (lds <= share) {
+        // large scenes: as many colour frames per wave as the workgroups of a CU leave room for (the scratch copy costs a
         // 64-byte write per push and four lines per pop: 430 GB of HBM traffic per C4 frame before this)
-        const int frames = (int)((80 * 1024 - lds) / ((size_t)COOP_WAVES * 16));
+        const int frames = (int)((share - lds) / ((size_t)COOP_WAVES * 16));
         a.coop_lds_stack = frames >= maxsp ? maxsp - 1 : frames >= 4 ? frames : 0;
         lds += (size_t)COOP_WAVES * 16 * (size_t)a.coop_lds_stack;
     }
@@ -1911,3 +1951,4 @@ hipError_t rt_launch_debug_intersect(const float4* hrec, int index, const float*
     hipLaunchKernelGGL(debug_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, hrec, index, rays, n, out8);
     return hipGetLastError();
 }
+#endif  // RT_RELAXED_TU

@@ -82,6 +82,7 @@ size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat);
 hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_classify(const KernelArgs& a, const LaunchTraits& t, unsigned int* cursor, unsigned int* list, hipStream_t stream);
 hipError_t rt_launch_direct(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
+hipError_t rt_launch_direct_relaxed(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);   // rt_kernels_relaxed.hip
 bool rt_launch_heavy_fits(int n_hit, int n_lights, int n_mat);
 bool rt_launch_coop_fits(int n_hit, int n_lights, int n_mat);
 bool rt_launch_rays_fits(int n_hit, int n_lights, int n_mat);

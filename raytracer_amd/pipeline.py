@@ -74,6 +74,9 @@ class FramePipeline:
         self.comm = comm
         self._gathered = None
         self._frame = None
+        # per frame of the last run(): time of the gather + reassembly step -- device time from HIP events when it went
+        # through rt_gather_rows, wall time of the torch.distributed gather + rt_deinterleave_bands otherwise
+        self.gather_ms = []
 
     def _buffers(self):
         """rank 0's gather and frame buffers, allocated once (no allocation inside the frame loop)"""
@@ -129,6 +132,8 @@ class FramePipeline:
         for t in threads:
             t.start()
         last = None
+        import time
+        self.gather_ms = []
         try:
             for k in range(n_frames):
                 slot = k % B
@@ -136,6 +141,7 @@ class FramePipeline:
                 if failed:
                     raise failed[0]
                 block = self.blocks[slot]
+                t_gather = time.perf_counter()
                 if self.comm is not None and nranks > 1:
                     W = block.shape[1]
                     bpp = block.element_size() * (block.shape[2] if block.dim() > 2 else 1)
@@ -152,6 +158,10 @@ class FramePipeline:
                     elif block.is_cuda:
                         # the block goes back to the producers: the send must have read it
                         torch.cuda.current_stream(block.device).synchronize()
+                if self.comm is not None and nranks > 1:
+                    self.gather_ms.append(self.renderer.last_gather_ms)
+                else:
+                    self.gather_ms.append((time.perf_counter() - t_gather) * 1e3)
                 free[slot].release()
                 if rank == 0 and on_frame is not None:
                     on_frame(first_frame + k, last)

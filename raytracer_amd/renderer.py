@@ -165,6 +165,20 @@ class Renderer:
         if comm:
             self._lib.rt_comm_destroy(ctypes.c_void_p(comm))
 
+    @staticmethod
+    def comm_count(comm):
+        """ncclCommCount: the number of ranks the communicator spans, as RCCL sees it"""
+        n = ctypes.c_int32(0)
+        rc = _abi.load().rt_comm_count(ctypes.c_void_p(comm), ctypes.byref(n))
+        if rc != 0:
+            raise _abi.RtError(rc, "rt_comm_count")
+        return int(n.value)
+
+    @property
+    def last_gather_ms(self):
+        """device time of this context's last gather_rows (RCCL group + reassembly), from HIP events on its stream"""
+        return float(self._lib.rt_last_gather_ms(self._h))
+
     def gather_rows(self, comm, rank, nranks, block, gathered, frame_out, width, height, bytes_per_pixel, band_rows, rows_per_rank):
         """rt_gather_rows: this rank's packed band block to rank 0 (grouped ncclSend / ncclRecv on the context's stream),
         reassembled into frame_out there.  block / gathered / frame_out: device tensors (gathered, frame_out: rank 0)."""

@@ -639,6 +639,9 @@ def test_gather_rows_over_rccl_single_rank(rt):
             frame.zero_()
             rt.gather_rows(comm, 0, 1, block, gathered, frame, W, H, 3, band, rpr)
             assert np.array_equal(frame.cpu().numpy(), want)
+        # what bench.py --gpus N reports about the transport: the ranks RCCL itself counts, the gather's device time
+        assert ra.Renderer.comm_count(comm) == 1
+        assert 0.0 < rt.last_gather_ms < 1000.0
         # no communicator, one rank: reassembled straight from the block
         frame.zero_()
         rt.gather_rows(None, 0, 1, block, None, frame, W, H, 3, band, rpr)

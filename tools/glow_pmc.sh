@@ -6,7 +6,9 @@ timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/d -o d -- python3 tools/glow_time.py > $OUT/d.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/e -o e -- python3 tools/glow_time.py > $OUT/e.log 2>&1 || exit 1
 python3 - <<PY
-import csv, json, collections
+import csv, json, collections, sys
+sys.path.insert(0, ".")
+from bench import kernel_source_hash
 tot = collections.defaultdict(float); per = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = 4.0                                   # glow_time.py applies the glow four times
 for f in ("$OUT/d/d_counter_collection.csv", "$OUT/e/e_counter_collection.csv"):
@@ -14,7 +16,7 @@ for f in ("$OUT/d/d_counter_collection.csv", "$OUT/e/e_counter_collection.csv"):
         if "glow_" not in r["Kernel_Name"]: continue
         tot[r["Counter_Name"]] += float(r["Counter_Value"]) / calls
         per[r["Kernel_Name"][:40]][r["Counter_Name"]] += float(r["Counter_Value"]) / calls
-out = {"fetch_kb": tot["FETCH_SIZE"], "write_kb": tot["WRITE_SIZE"], "hbm_bytes": (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024,
+out = {"kernel_source_sha256": kernel_source_hash(), "fetch_kb": tot["FETCH_SIZE"], "write_kb": tot["WRITE_SIZE"], "hbm_bytes": (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024,
        "per_kernel_kb": {k: dict(v) for k, v in per.items()}, "note": "per rt_apply_glow call on a 4K frame; hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB"}
 json.dump(out, open("profiles/pmc_glow_4k.json", "w"), indent=1)
 print(json.dumps(out)[:600])

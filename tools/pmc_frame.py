@@ -17,7 +17,7 @@ launches = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_*_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "rt::" not in k:
+        if "rt::" not in k and "rt_relaxed::" not in k:
             continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[k][r["Counter_Name"]].add(r["Dispatch_Id"])
@@ -39,8 +39,12 @@ for k, v in kernels.items():
 g = tot.get
 lane_util = g("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * g("SQ_ACTIVE_INST_VALU", 1))
 fp = {c: g("SQ_INSTS_VALU_" + c + "_F32", 0.0) for c in ("ADD", "MUL", "FMA", "TRANS")}
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash
 out = {
     "workload": workload, "profile": "prof_" + tag, "frames_in_run": frames,
+    # the kernels these counts belong to: bench.py prices a run with them only if its tree hashes the same
+    "kernel_source_sha256": kernel_source_hash(),
     "per_frame": {
         "valu_wave_instructions": g("SQ_INSTS_VALU", 0),
         "salu_wave_instructions": g("SQ_INSTS_SALU", 0),

@@ -8,8 +8,8 @@ python3 - <<PY
 import csv,glob,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(set)
 for r in csv.DictReader(open("$OUT/a/a_counter_collection.csv")):
-    if "rt::" not in r["Kernel_Name"]: continue
-    k=r["Kernel_Name"][9:75]+"|grid"+r["Grid_Size"]
+    if "rt::" not in r["Kernel_Name"] and "rt_relaxed::" not in r["Kernel_Name"]: continue
+    k=r["Kernel_Name"].replace("void ","")[:70]+"|grid"+r["Grid_Size"]
     agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     if r["Counter_Name"]=="GRBM_GUI_ACTIVE": agg[k]["_ms"]+=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
 for k,v in sorted(agg.items(), key=lambda kv:-kv[1]["_ms"])[:8]:

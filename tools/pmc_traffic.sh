@@ -12,8 +12,8 @@ import csv,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(lambda: collections.defaultdict(set))
 for c in ("FETCH_SIZE","WRITE_SIZE"):
     for r in csv.DictReader(open("$OUT/%s/a_counter_collection.csv" % c)):
-        if "rt::" not in r["Kernel_Name"]: continue
-        k=r["Kernel_Name"][9:75]+"|grid"+r["Grid_Size"]
+        if "rt::" not in r["Kernel_Name"] and "rt_relaxed::" not in r["Kernel_Name"]: continue
+        k=r["Kernel_Name"].replace("void ","")[:70]+"|grid"+r["Grid_Size"]
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k][r["Counter_Name"]].add(r["Dispatch_Id"])
 for k,v in sorted(agg.items(), key=lambda kv:-(2*kv[1]["FETCH_SIZE"]+kv[1]["WRITE_SIZE"]))[:8]:
     f=v["FETCH_SIZE"]/max(1,len(n[k]["FETCH_SIZE"])); w=v["WRITE_SIZE"]/max(1,len(n[k]["WRITE_SIZE"]))

@@ -7,7 +7,7 @@ TAG=${1:-r01}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $*"
 
 run() {  # name, rocprof args...
     local name=$1; shift
