@@ -285,7 +285,7 @@ def main():
     import torch.distributed as dist
     import raytracer_amd as ra
     from raytracer_amd import bands
-    from raytracer_amd.pipeline import FramePipeline, sleeping_waits
+    from raytracer_amd.pipeline import FramePipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -323,11 +323,8 @@ def main():
         # (many2048 1080p/32spp: 0.84 s per frame against 0.92 s with three in flight)
         in_flight = 1
     # one host thread per frame in flight waits inside rt_render_rows most of the time: under RT_FLAG_SEQUENCE the
-    # library polls an event with short naps there ("nap").  RT_BENCH_WAITS=sleep: HIP's process-wide sleeping waits on
-    # top (raytracer_amd/pipeline.py sleeping_waits; not the default -- a process that mixed the kinds of wait has hung)
-    host_waits = os.environ.get("RT_BENCH_WAITS", "nap") if in_flight > 1 else "spin"
-    if host_waits == "sleep":
-        sleeping_waits(local_rank)
+    # library polls an event with short naps there ("nap") instead of HIP's busy-polling wait ("spin")
+    host_waits = "nap" if in_flight > 1 else "spin"
     rts = [ra.Renderer(local_rank) for _ in range(in_flight)]
     for r in rts:
         r.upload_scene(scene)

@@ -154,9 +154,11 @@ int rt_render_rows(rt_ctx* ctx, const rt_camera35f* cam, const rt_params* params
                    uint8_t* rgb_out, float* emission_out, rt_counters* counters);
 
 /* rt_render_rows for callers that cannot allocate.  It has no counterpart in the reference: it is for callers that
- * may not call hipMalloc where they render -- code under HIP graph capture, tight serving loops, harnesses that forbid
- * allocation.  Same kernels, same bytes as rt_render_rows, but the call allocates nothing (no hipMalloc / hipFree, no
- * stream or event creation): the per-frame device state and the pixel classes (a class per pixel and the list of
+ * may not call hipMalloc where they render -- tight serving loops, harnesses that forbid allocation, code that sets up
+ * a HIP graph capture elsewhere in the process and must not disturb the allocator meanwhile.  The call itself is
+ * synchronous (it waits on the context's stream and reads a few words back, like rt_render_rows) and therefore cannot
+ * itself be captured into a graph.  Same kernels, same bytes as rt_render_rows, but the call allocates nothing (no
+ * hipMalloc / hipFree, no stream or event creation): the per-frame device state and the pixel classes (a class per pixel and the list of
  * bounce pixels, 6 bytes per pixel) live in a static device array of RT_STATIC_MAX_PIXELS * 6 + 4096 bytes that every
  * GPU the library runs on holds until the process ends.
  *   - rgb_dev / emission_dev must be DEVICE pointers on the context's GPU (host outputs would need a staging buffer);

@@ -830,14 +830,23 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                         // this frame's direct kernel: onto the next shared stream, behind the classification (ev_list);
                         // the context's stream waits for it at the end of the frame (ev_gen).  One lock around the
                         // three calls, so that no other context's kernel gets between this kernel and its event.
-                        std::lock_guard<std::mutex> lock(g_direct_mutex);
-                        SharedDirect& sd = g_direct[ctx->device];
-                        hipStream_t& ds = sd.s[sd.turn++ % (unsigned)shared_n];
-                        if (!ds) HIP_TRY(ctx, hipStreamCreateWithFlags(&ds, hipStreamNonBlocking));
-                        ctx->shared_used = ds;
-                        HIP_TRY(ctx, hipStreamWaitEvent(ds, ctx->ev_list, 0));
-                        HIP_TRY(ctx, launch_direct(a, t, ds));
-                        HIP_TRY(ctx, hipEventRecord(ctx->ev_gen, ds));
+                        // (no early return with the lock held: a failing call is reported after the lock is gone, and a
+                        // stream's turn only advances once the stream exists)
+                        hipError_t e = hipSuccess;
+                        {
+                            std::lock_guard<std::mutex> lock(g_direct_mutex);
+                            SharedDirect& sd = g_direct[ctx->device];
+                            hipStream_t& ds = sd.s[sd.turn % (unsigned)shared_n];
+                            if (!ds) e = hipStreamCreateWithFlags(&ds, hipStreamNonBlocking);
+                            if (e == hipSuccess) {
+                                ++sd.turn;
+                                ctx->shared_used = ds;
+                                e = hipStreamWaitEvent(ds, ctx->ev_list, 0);
+                                if (e == hipSuccess) e = launch_direct(a, t, ds);
+                                if (e == hipSuccess) e = hipEventRecord(ctx->ev_gen, ds);
+                            }
+                        }
+                        HIP_TRY(ctx, e);
                         direct_done = true; second = true;
                     }
                     // one launch owns the whole list (one dispatch less per frame; the split below buys latency for a

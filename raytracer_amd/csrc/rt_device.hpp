@@ -610,6 +610,11 @@ __device__ __forceinline__ bool cluster_may_hit(float4 c, float4 h, v3 ro, v3 rd
 __device__ __forceinline__ unsigned long long cluster_mask(const SceneLds& sc, v3 ro, v3 rd)
 {
     const int lane = (int)(threadIdx.x & 63);
+    // no boxes staged (stage_scene without stage_scene_sorted): every round of 64 is visited, nothing is skipped
+    if (sc.clusters == nullptr || sc.n_clusters <= 0) {
+        const int rounds = (sc.n_hit + 63) / 64;
+        return rounds >= 64 ? ~0ull : (1ull << rounds) - 1ull;
+    }
     bool visit = lane < sc.n_clusters;            // (n_clusters = ceil(n_hit / 64) wherever the cooperative scans run)
     if (visit) visit = cluster_may_hit(((const float4*)sc.clusters)[2 * lane], ((const float4*)sc.clusters)[2 * lane + 1], ro, rd);
     return __ballot(visit);

@@ -51,30 +51,71 @@ int main(int argc, char** argv)
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
 
-    // --ranks N: ranks 1 .. N-1 are forked here, before anything touches a GPU; rank 0 makes the communicator's id and
-    // hands it to them through pipes
+    // --ranks N: ranks 1 .. N-1 are forked here, before anything touches a GPU.  Then a handshake over pipes, so that no
+    // rank enters RCCL unless every rank can: each rank opens (and closes) a context on its GPU and reports to rank 0;
+    // rank 0 makes the communicator's id and answers every rank with go / no-go and the id.  A rank without a GPU, or a
+    // failing rt_comm_unique_id, ends the job with exit code 1 on every rank instead of leaving the others waiting in
+    // ncclCommInitRank.
     int rank = 0;
     unsigned char commId[RT_COMM_ID_BYTES] = { 0 };
     std::vector<pid_t> kids;
     if (ranks > 1) {
-        std::vector<int> rd((size_t)ranks, -1), wr((size_t)ranks, -1);
-        for (int r = 1; r < ranks; ++r) { int fd[2]; if (pipe(fd) != 0) { std::perror("pipe"); return 2; } rd[(size_t)r] = fd[0]; wr[(size_t)r] = fd[1]; }
+        std::vector<int> down_rd((size_t)ranks, -1), down_wr((size_t)ranks, -1), up_rd((size_t)ranks, -1), up_wr((size_t)ranks, -1);
+        for (int r = 1; r < ranks; ++r) {
+            int d[2], u[2];
+            if (pipe(d) != 0 || pipe(u) != 0) { std::perror("pipe"); return 2; }
+            down_rd[(size_t)r] = d[0]; down_wr[(size_t)r] = d[1]; up_rd[(size_t)r] = u[0]; up_wr[(size_t)r] = u[1];
+        }
         for (int r = 1; r < ranks && rank == 0; ++r) {
             pid_t pid = fork();
             if (pid < 0) { std::perror("fork"); return 2; }
-            if (pid == 0) rank = r; else kids.push_back(pid);
+            if (pid == 0) { rank = r; kids.clear(); }     // (a child inherits the list of its elder siblings: not its to wait for)
+            else kids.push_back(pid);
         }
-        if (rank == 0) {
-            int rc = rt_comm_unique_id(commId);
-            if (rc != RT_OK) { std::fprintf(stderr, "rt_comm_unique_id failed: %s\n", rt_strerror(rc)); std::memset(commId, 0, sizeof commId); }
-            for (int r = 1; r < ranks; ++r) { if (write(wr[(size_t)r], commId, sizeof commId) != (ssize_t)sizeof commId) std::perror("write"); close(wr[(size_t)r]); close(rd[(size_t)r]); }
-            if (rc != RT_OK) return 1;
-        } else {
-            for (int r = 1; r < ranks; ++r) { close(wr[(size_t)r]); if (r != rank) close(rd[(size_t)r]); }
-            if (read(rd[(size_t)rank], commId, sizeof commId) != (ssize_t)sizeof commId) { std::fprintf(stderr, "rank %d: no communicator id\n", rank); return 1; }
-            close(rd[(size_t)rank]);
-        }
+        auto reap = [&kids]() {
+            bool ok = true;
+            for (pid_t pid : kids) { int wst = 0; if (waitpid(pid, &wst, 0) < 0 || !WIFEXITED(wst) || WEXITSTATUS(wst) != 0) ok = false; }
+            kids.clear();
+            return ok;
+        };
         st.device += rank;
+        rt_ctx* probe_ctx = nullptr;
+        const int have = rt_create(&probe_ctx, st.device);
+        if (have == RT_OK) rt_destroy(probe_ctx);
+        else std::fprintf(stderr, "rank %d: no context on GPU %d: %s\n", rank, st.device, rt_strerror(have));
+        unsigned char msg[1 + RT_COMM_ID_BYTES] = { 0 };
+        if (rank == 0) {
+            bool go = have == RT_OK;
+            for (int r = 1; r < ranks; ++r) {
+                close(down_rd[(size_t)r]); close(up_wr[(size_t)r]);
+                unsigned char ok = 0;
+                if (read(up_rd[(size_t)r], &ok, 1) != 1 || ok != 1) go = false;         // (a child that died reads as 0 bytes)
+                close(up_rd[(size_t)r]);
+            }
+            if (go) {
+                const int rc = rt_comm_unique_id(commId);
+                if (rc != RT_OK) { std::fprintf(stderr, "rt_comm_unique_id failed: %s\n", rt_strerror(rc)); go = false; }
+            }
+            msg[0] = go ? 1 : 0;
+            std::memcpy(msg + 1, commId, sizeof commId);
+            for (int r = 1; r < ranks; ++r) {
+                if (write(down_wr[(size_t)r], msg, sizeof msg) != (ssize_t)sizeof msg) std::perror("write");
+                close(down_wr[(size_t)r]);
+            }
+            if (!go) { (void)reap(); return 1; }
+        } else {
+            for (int r = 1; r < ranks; ++r) {
+                close(down_wr[(size_t)r]); close(up_rd[(size_t)r]);
+                if (r != rank) { close(down_rd[(size_t)r]); close(up_wr[(size_t)r]); }
+            }
+            const unsigned char ok = have == RT_OK ? 1 : 0;
+            if (write(up_wr[(size_t)rank], &ok, 1) != 1) std::perror("write");
+            close(up_wr[(size_t)rank]);
+            const bool got = read(down_rd[(size_t)rank], msg, sizeof msg) == (ssize_t)sizeof msg;
+            close(down_rd[(size_t)rank]);
+            if (!got || msg[0] != 1) { if (!got) std::fprintf(stderr, "rank %d: no answer from rank 0\n", rank); return 1; }
+            std::memcpy(commId, msg + 1, sizeof commId);
+        }
     }
 
     LoadedScene loaded;

@@ -23,6 +23,19 @@ inline vec3 operator-(const vec3& a) { return { -a.x, -a.y, -a.z }; }
 inline vec3 operator*(const vec3& a, float s) { return { a.x * s, a.y * s, a.z * s }; }
 inline vec3 operator*(float s, const vec3& a) { return { s * a.x, s * a.y, s * a.z }; }
 inline bool operator==(const vec3& a, const vec3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+// component-wise forms the reference's pixel loop and glow code spell (src/main.cpp:197, 313-319)
+inline vec3 operator*(const vec3& a, const vec3& b) { return { a.x * b.x, a.y * b.y, a.z * b.z }; }
+inline vec3 operator/(const vec3& a, const vec3& b) { return { a.x / b.x, a.y / b.y, a.z / b.z }; }
+inline vec3 operator/(const vec3& a, float s) { return { a.x / s, a.y / s, a.z / s }; }
+inline vec3& operator+=(vec3& a, const vec3& b) { a = a + b; return a; }
+inline vec3& operator*=(vec3& a, float s) { a = a * s; return a; }
+// detail/func_common.inl:20,29,244: min(x, y) = (y < x) ? y : x, max(x, y) = (x < y) ? y : x, clamp = min(max(x, lo), hi)
+template <class T> inline T min(T x, T y) { return (y < x) ? y : x; }
+template <class T> inline T max(T x, T y) { return (x < y) ? y : x; }
+inline vec3 clamp(const vec3& v, const vec3& lo, const vec3& hi)
+{
+    return { min(max(v.x, lo.x), hi.x), min(max(v.y, lo.y), hi.y), min(max(v.z, lo.z), hi.z) };
+}
 
 // detail/func_geometric.inl:48-55: tmp = a * b; tmp.x + tmp.y + tmp.z
 inline float dot(const vec3& a, const vec3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }

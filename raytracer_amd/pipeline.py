@@ -21,35 +21,6 @@ import torch
 from . import bands
 
 
-def sleeping_waits(device=0, on=True):
-    """Opt-in, for a process that has created no HIP stream yet: host threads that wait for `device` sleep instead of
-    spin.  on=False: back to HIP's default (hipDeviceScheduleAuto).
-
-    Not needed for the library's own waits: under RT_FLAG_SEQUENCE rt_render_rows polls an event with short naps
-    (DESIGN.md section 6), which is what keeps 16 producers from occupying 12 CPUs.  This switch is HIP's own,
-    hipSetDeviceFlags(hipDeviceScheduleBlockingSync), and covers every wait of the process (torch's too): per device
-    and process-wide, so the host application's to set, not the library's.  Measured on ROCm 7.2
-    (tools/exp/wait_cpu.hip): the flag is read when a wait starts, only streams created under it are slept on,
-    hipEventBlockingSync on an event does nothing by itself -- and a process that switched after it had created and
-    destroyed many streams under the default HUNG in hipStreamSynchronize on an idle stream (a GPU test that did so;
-    removed).  Hence not the default anywhere: bench.py takes it with RT_BENCH_WAITS=sleep, tools/pipeline_time.py
-    with RT_WAITS=sleep, both before their first context.  The symbol
-    is taken through the C-ABI library's handle, i.e. from the HIP runtime that library uses."""
-    import ctypes
-    from . import _abi
-    lib = _abi.load()
-    cur = ctypes.c_int(0)
-    hipDeviceScheduleBlockingSync = 0x4
-    for call, args in ((lib.hipGetDevice, (ctypes.byref(cur),)), (lib.hipSetDevice, (ctypes.c_int(int(device)),)),
-                       (lib.hipSetDeviceFlags, (ctypes.c_uint(hipDeviceScheduleBlockingSync if on else 0),))):
-        call.restype = ctypes.c_int
-        err = call(*args)
-        if err != 0:
-            raise RuntimeError("sleeping_waits: HIP error %d" % err)
-    lib.hipSetDevice.restype = ctypes.c_int
-    lib.hipSetDevice(cur)
-
-
 class FramePipeline:
     """render(worker, block, k) must fill `block` with this rank's packed bands of frame k, using the resources of
     producer `worker` (0 <= worker < workers: its Renderer context), and return when they are in memory

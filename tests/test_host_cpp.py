@@ -58,6 +58,138 @@ def test_reference_style_driver_compiles_against_host_headers():
         assert r.returncode == 0, r.stderr
 
 
+MAIN_STYLE_TU = r'''
+// written the way the reference's main.cpp is around its renderer: tile records popped and recomposed with memcpy
+// (src/main.cpp:375-395), the glow's upscaled emission added with pixel::Add (src/main.cpp:191-198), a pixel loop that ends
+// in pixel::Set / emissionPixel::Set (src/main.cpp:318-319), rand.h's curandState seeded per pixel (src/main.cpp:304)
+#define WIDTH 64
+#define HEIGHT 32
+#define SAMPLES 2
+#define MAXDEPTH 4
+#include "renderer.h"
+#include "rand.h"
+#include "hittables/hittablesList.h"
+#include "hittables/sphere.h"
+#include "lights/lightsList.h"
+#include "lights/directionalLight.h"
+#include <cstring>
+#include <cstdlib>
+struct CountingSphere : public Sphere      // user code may override the reference's virtuals
+{
+    using Sphere::Sphere;
+    bool intersect(const Ray& ray, RayHit& hit) const override { hit.copy(RayHit(ray.direction.z)); return false; }
+    bool hasIntersect(const Ray&) const override { return false; }
+};
+int main()
+{
+    const int tileSize = 16;
+    pixel* image = (pixel*)malloc(WIDTH * HEIGHT * sizeof(pixel));
+    emissionPixel* emissionImg = (emissionPixel*)malloc(WIDTH * HEIGHT * sizeof(emissionPixel));
+    pixel* tile = new pixel[tileSize * tileSize];
+    emissionPixel* emissionTile = new emissionPixel[tileSize * tileSize];
+    for (int nY = 0; nY < tileSize; ++nY)
+        for (int nX = 0; nX < tileSize; ++nX)
+        {
+            int x = nX, y = nY;
+            curandState randState(x + y * WIDTH);
+            HitColorGlow result;
+            for (int i = 0; i < SAMPLES; ++i)
+            {
+                HitColorGlow sample;
+                sample.color = glm::vec3(randState.randomUnit());
+                result.color            += glm::clamp(sample.color,    glm::vec3(0.0f), glm::vec3(1.0f));
+                result.emission         += glm::clamp(sample.emission, glm::vec3(0.0f), glm::vec3(1.0f));
+                result.emissionStrenght += sample.emissionStrenght;
+            }
+            tile        [nX + nY * tileSize].Set(result.color    / glm::vec3(SAMPLES));
+            emissionTile[nX + nY * tileSize].Set(result.emission / glm::vec3(SAMPLES), result.emissionStrenght / SAMPLES);
+        }
+    int x = 0, y = 0;
+    for (int i = 0; i < tileSize; ++i)
+    {
+        memcpy(&image[x * tileSize + (y * tileSize + i) * WIDTH], &tile[i * tileSize], tileSize * sizeof(pixel));
+        memcpy(&emissionImg[x * tileSize + (y * tileSize + i) * WIDTH], &emissionTile[i * tileSize], tileSize * sizeof(emissionPixel));
+    }
+    for (int yy = 0; yy < HEIGHT; ++yy)
+        for (int xx = 0; xx < WIDTH; ++xx)
+        {
+            emissionPixel& p = emissionImg[xx + yy * WIDTH];
+            image[xx + yy * WIDTH].Add(p.emission * glm::vec3(0.1f) * p.strenght);
+        }
+    Hittable** l_world = new Hittable*[1];
+    l_world[0] = new CountingSphere({ 0.0f, 1.0f, -4.0f }, 1.0f, 0);
+    Hittable* world = new HittablesList(l_world, 1);
+    Ray ray; RayHit hit;
+    bool any = l_world[0]->intersect(ray, hit) || l_world[0]->hasIntersect(ray);
+    writePPM("/dev/null", image, WIDTH, HEIGHT);
+    delete world; delete[] l_world; delete[] tile; delete[] emissionTile; free(image); free(emissionImg);
+    return any;
+}
+'''
+
+POD_CHECK_TU = r'''
+#include "structs.h"
+#include <cstdio>
+int main()
+{
+    // pixel::Set: double sqrt, double multiply, truncation (src/structs.h:12-17; SURVEY.md fact 7); Add saturates in int
+    const float vals[] = { 0.0f, 1.0f, 0.25f, 0.5f, 0.999999f, 1.5378700e-05f, 0.61f };
+    for (float v : vals) { pixel p; p.Set(glm::vec3(v)); std::printf("%d ", (int)p.x); }
+    pixel q; q.Set(glm::vec3(0.81f)); q.Add(glm::vec3(0.04f)); std::printf("| %d ", (int)q.x);
+    q.Add(glm::vec3(1.0f)); std::printf("%d ", (int)q.y);
+    emissionPixel e; e.Set(glm::vec3(0.1f, 0.2f, 0.3f), 4.5f); emissionPixel f; f.Set(e);
+    std::printf("| %g %g\n", f.emission.y, f.strenght);
+    std::printf("%zu %zu %zu %zu %zu\n", sizeof(pixel), sizeof(emissionPixel), sizeof(Ray), sizeof(RayHit), sizeof(HitColorGlow));
+    return 0;
+}
+'''
+
+
+def test_main_style_recompose_and_pixel_ops_compile_against_host_headers():
+    """SURVEY 7.2 / VERDICT round 2: a main.cpp-shaped driver -- recompose, pixel::Set / Add, emissionPixel::Set, HitColorGlow,
+    curandState, overriding Hittable::intersect / hasIntersect -- compiles unchanged against raytracer_amd/host."""
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "main_like.cpp")
+        with open(src, "w") as fh:
+            fh.write(MAIN_STYLE_TU)
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", HOST, "-I", os.path.join(ROOT, "include"), src],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
+def test_host_pods_have_the_reference_layouts_and_pixel_arithmetic():
+    """sizes per SURVEY.md section 2 (probe): pixel 3, emissionPixel 16, Ray 24, RayHit 36, HitColorGlow 28; pixel::Set is the
+    double-sqrt truncation the kernels and the oracle implement (numpy float64 restatement here), Add saturates at 255."""
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "pods.cpp"), os.path.join(td, "pods")
+        with open(src, "w") as fh:
+            fh.write(POD_CHECK_TU)
+        r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", HOST, src, "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split("\n")
+    vals = np.asarray([0.0, 1.0, 0.25, 0.5, 0.999999, 1.5378700e-05, 0.61], dtype=np.float32)
+    want = [int(np.sqrt(np.float64(v)) * 255.0) for v in vals]
+    head, mid, tail = out[0].split("|")
+    assert [int(t) for t in head.split()] == want
+    q = int(np.sqrt(np.float64(np.float32(0.81))) * 255.0) + int(np.sqrt(np.float64(np.float32(0.04))) * 255.0)
+    assert [int(t) for t in mid.split()] == [min(q, 255), 255]
+    assert tail.split() == ["0.2", "4.5"]
+    assert out[1].split() == ["3", "16", "24", "36", "28"]
+
+
+def test_cpp_driver_ranks_without_gpus_fail_together_instead_of_hanging():
+    """rt_render --ranks 3 where some rank has no GPU (here: none has; on the one-GPU box ranks 1 and 2): the handshake in
+    front of the communicator ends every rank with exit code 1 -- no rank is left waiting in ncclCommInitRank, the parent
+    reaps its children (children do not wait for their elder siblings: ADVICE round 2)."""
+    if not os.path.exists(EXE):
+        pytest.skip("raytracer_amd/host/rt_render not built")
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([EXE, "--ranks", "3", "--w", "64", "--h", "32", "--samples", "1", "--out", os.path.join(td, "o.ppm")],
+                           capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert "rank 2: no context on GPU 2" in r.stderr and "rank 1: no context on GPU 1" in r.stderr
+
+
 def _read_ppm(path):
     with open(path, "rb") as fh:
         data = fh.read()

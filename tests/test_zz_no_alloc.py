@@ -60,6 +60,34 @@ def test_static_entry_point_equals_render_rows_twice_in_a_row():
         assert np.array_equal(a, b)
 
 
+def test_static_entry_point_leaves_free_device_memory_unchanged():
+    """What the entry point is for: a context whose FIRST render is the static call, then a call with more bounce pixels
+    than the one before, then a smaller one -- the device's free memory (hipMemGetInfo) is the same before and after
+    each.  (rt_render_rows on the same fresh context does allocate: its pixel classes.)"""
+    import torch
+    torch.zeros(1, device="cuda:0")
+    sc = scenes.glass_mirror()
+    with ra.Renderer(0) as rt:
+        rt.upload_scene(sc)
+        outs = {(W, H): torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0") for (W, H) in ((160, 90), (640, 360), (96, 48))}
+        ems = {k: torch.zeros(v.shape[:2] + (4,), dtype=torch.float32, device="cuda:0") for k, v in outs.items()}
+        torch.cuda.synchronize()
+        deltas = []
+        for (W, H), spp in (((160, 90), 4), ((640, 360), 8), ((96, 48), 2)):
+            cam = ra.camera35f(sc, W, H)
+            p = rt.params(W, H, spp, 12, 1)
+            free0, _ = torch.cuda.mem_get_info(0)
+            rt.render_rows_static(cam, p, outs[(W, H)], ems[(W, H)])
+            free1, _ = torch.cuda.mem_get_info(0)
+            deltas.append(free0 - free1)
+        assert deltas == [0, 0, 0], deltas
+        # the allocating entry point on the same context, for contrast: it has to make room for the pixel classes
+        free0, _ = torch.cuda.mem_get_info(0)
+        rt.render_rows(ra.camera35f(sc, 640, 360), rt.params(640, 360, 8, 12, 1), outs[(640, 360)], ems[(640, 360)])
+        free1, _ = torch.cuda.mem_get_info(0)
+        assert free0 - free1 > 0
+
+
 def test_static_entry_point_limits():
     import torch
     with ra.Renderer(0) as rt:

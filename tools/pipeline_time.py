@@ -3,7 +3,7 @@
     tools/pipeline_time.py <workload> <frames> <F> [<F> ...]        F = producers (contexts)
 RT_EMULATE_RANKS=N renders rank 0's share of an N-GPU frame (cyclic 16-row bands), i.e. what one rank of an N-GPU
 job does per frame minus the RCCL gather.  RT_HW_QUEUES sets GPU_MAX_HW_QUEUES before HIP starts; RT_FLAGS = rt_params.flags
-(include/rt_amd.h) for A/B runs; RT_CHECK_ALL=1 checksums every frame (slower: a check, not a timing); RT_WAITS=sleep: sleeping_waits (raytracer_amd/pipeline.py) instead of HIP's polling waits."""
+(include/rt_amd.h) for A/B runs; RT_CHECK_ALL=1 checksums every frame (slower: a check, not a timing)."""
 import os
 import sys
 import time
@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import raytracer_amd as ra
 from raytracer_amd import bands
-from raytracer_amd.pipeline import FramePipeline, sleeping_waits
+from raytracer_amd.pipeline import FramePipeline
 from bench import WORKLOADS
 
 wl, frames = sys.argv[1], int(sys.argv[2])
@@ -24,8 +24,6 @@ ranks = int(os.environ.get("RT_EMULATE_RANKS", "1"))
 cam = ra.camera35f(scene, W, H)
 rpr = bands.rows_per_rank(H, 16, ranks)
 ref = None
-if os.environ.get("RT_WAITS", "spin") == "sleep":
-    sleeping_waits(0)
 for F in [int(f) for f in sys.argv[3:]] or [1]:
     rts = [ra.Renderer(0) for _ in range(F)]
     for rt in rts:
