@@ -110,13 +110,8 @@ typedef struct {
                                            keep their generators in scratch rather than LDS; one launch instead of two
                                            side by side; the calling thread naps between polls while it waits)      */
 
-#define RT_FLAG_RAYS_LISTED            32 /* bounce pixels of small scenes a lane per ray, 16 lanes per pixel, each ray
-                                           from a guessed place in the pixel's rand() sequence (rays_kernel): same
-                                           bytes, shorter latency for a small frame on its own, more work per ray   */
-#define RT_FLAG_FORCE_SOLO             64 /* test hook: every bounce pixel leaves the listed kernel after its first four
-                                           samples for a wave of its own (the route of long pixels whose draw counts
-                                           differ from sample to sample)                                             */
-
+/* (32 and 64 belonged to two alternative routes for bounce pixels -- a lane per ray, a wave per unsteady pixel -- that were
+ * measured in round 2, had no default user and were removed in round 3: DESIGN.md section 5, 3b / 3c) */
 #define RT_FLAG_RELAXED               128 /* opt-in: pixels whose primary rays cannot bounce (the direct kernel's, which draw
                                            no random numbers) are rendered with relaxed float arithmetic -- fused
                                            multiply-adds, the hardware's 1-ulp sqrt / reciprocal -- instead of the

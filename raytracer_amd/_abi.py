@@ -16,8 +16,6 @@ RT_FLAG_COUNT_EXECUTED = 2
 RT_FLAG_SINGLE_KERNEL = 4
 RT_FLAG_FORCE_SAMPLE_PARALLEL = 8
 RT_FLAG_SEQUENCE = 16
-RT_FLAG_RAYS_LISTED = 32
-RT_FLAG_FORCE_SOLO = 64
 RT_FLAG_RELAXED = 128
 RT_COMM_ID_BYTES = 128
 RT_ERR_RCCL = -9

@@ -41,15 +41,6 @@
 #ifndef RT_HEAVY_MIN_WORK_SEQ
 #define RT_HEAVY_MIN_WORK_SEQ RT_HEAVY_MIN_WORK
 #endif
-// draws a pixel with unsteady counts is expected to make in its remaining samples for it to get a wave of its own.
-// 0: the route is off, which is the default -- measured: it shortens the listed kernel but not
-// the frame (glass 1080p alone 171 -> 165 ms at 20000, the wave that renders the longest pixel from its first sample
-// takes 82 ms by itself) and costs throughput with frames in flight (31 -> 39 ms per frame).  RT_SOLO_MIN_WORK in the
-// environment sets it for A/B runs; RT_FLAG_FORCE_SOLO sends every bounce pixel that way (tests).
-#ifndef RT_SOLO_MIN_WORK
-#define RT_SOLO_MIN_WORK 0u
-#endif
-
 struct rt_ctx {
     int device = -1;
     hipStream_t stream = nullptr;      // everything but the listed general kernel
@@ -105,11 +96,9 @@ struct rt_ctx {
 #define RT_DEV_WORDS_BYTES (5 * sizeof(unsigned long long) + sizeof(int) * 2)
 // Everything a frame needs zeroed sits in one block behind them, so that one fill per frame does it (under load every
 // small dispatch waits its turn for tens of microseconds): the sample-parallel route's counters (heavy_count,
-// fallback_count, pool words used: 16 bytes; solo_count and the solo launch's queue word: 8 bytes + 8 of padding), then
-// the pixel classes' histogram and cursor (2 * RT_MAX_KEYS words).
+// fallback_count, pool words used: 16 bytes), then the pixel classes' histogram and cursor (2 * RT_MAX_KEYS words).
 #define RT_DEV_HEAVY_AT  RT_DEV_WORDS_BYTES
-#define RT_DEV_SOLO_AT   (RT_DEV_HEAVY_AT + 16)
-#define RT_DEV_HIST_AT   (RT_DEV_SOLO_AT + 16)
+#define RT_DEV_HIST_AT   (RT_DEV_HEAVY_AT + 16)
 #define RT_DEV_STATE_BYTES (RT_DEV_HIST_AT + 2 * RT_MAX_KEYS * sizeof(unsigned int))
 
 // rt_render_rows_static (include/rt_amd.h): the per-frame device state and the pixel classes of a call that may not
@@ -232,10 +221,10 @@ void fill_args(const rt_ctx* ctx, const rt_camera35f* cam, const rt_params* p, K
     a.hrec = ctx->d_hrec; a.lights = ctx->d_lights; a.mats = ctx->d_mats;
     a.rgb = nullptr; a.emission = nullptr; a.counters = words; a.fault = fault;
     a.queue = (unsigned int*)(fault + 1);                // the word after it: reset with the counters
-    a.keys = nullptr; a.hist = nullptr; a.list = nullptr; a.list_count = 0; a.list_count_dev = nullptr;
+    a.keys = nullptr; a.hist = nullptr; a.list = nullptr; a.list_count = 0;
     a.fallback_count = nullptr; a.fallback_list = nullptr; a.listed_mode = 0;
     a.heavy_count = nullptr; a.heavy_rec = nullptr; a.heavy_pool = nullptr; a.heavy_pool_used = nullptr;
-    a.solo_list = nullptr; a.solo_count = nullptr; a.solo_cap = 0; a.solo_min_work = 0; a.coop_lds_stack = 0;
+    a.coop_lds_stack = 0;
     a.heavy_pool_words = 0; a.heavy_cap = 0; a.heavy_min_work = 0;
     a.prim = ctx->d_prim;
     a.order = ctx->d_order;
@@ -743,13 +732,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                 // Large scenes: one wave per listed pixel, the lanes share every scan of the scene (coop_kernel)
                 const bool coop = ctx->n_hit >= RT_COOP_MIN_HIT && rt_launch_coop_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)
                                   && !force;
-                // RT_FLAG_RAYS_LISTED: a lane per ray, 16 lanes per pixel, draws read at guessed places of the pixel's rand()
-                // sequence (rays_kernel): the shortest path to a small frame's last pixel (an eighth of the 4K frame alone
-                // 2.3 instead of 3.2 ms), at more instructions per ray (whole 4K frame 7.7 instead of 5.7 ms alone, 7.2
-                // instead of 5.3 ms in a sequence): for callers who render small shares one at a time.
-                const bool rays = !coop && !no_alloc && !force && (p->flags & RT_FLAG_RAYS_LISTED) != 0
-                                  && rt_launch_rays_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat);
-                if (!coop && !rays && !no_alloc && p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
+                if (!coop && !no_alloc && p->samples >= 8 && p->samples <= 64 && rt_launch_heavy_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
                     // records + a pool for the pixels' written-out rand() sequences
                     size_t cap = n_listed < RT_HEAVY_CAP ? n_listed : RT_HEAVY_CAP;
                     // the pool follows the list: 64 bytes per listed pixel and sample (a pixel that draws 8 numbers per
@@ -779,34 +762,14 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     double min_work = ((p->flags & RT_FLAG_SEQUENCE) && seq_min_work >= 1.0 ? seq_min_work : (double)RT_HEAVY_MIN_WORK)
                                       / (per_bounce > 1.0 ? per_bounce : 1.0);
                     g2.heavy_min_work = force ? 0u : (unsigned int)(min_work < 1.0 ? 1.0 : min_work > 4.0e9 ? 4.0e9 : min_work);
-                    // long pixels whose draw counts differ from sample to sample: a wave each (coop_kernel over solo_list)
-                    static const unsigned int solo_work = getenv("RT_SOLO_MIN_WORK") ? (unsigned int)atoll(getenv("RT_SOLO_MIN_WORK")) : RT_SOLO_MIN_WORK;
-                    const bool force_solo = (p->flags & RT_FLAG_FORCE_SOLO) != 0;
-                    if ((solo_work > 0 || force_solo) && !force && rt_launch_coop_fits(ctx->n_hit, ctx->n_lights, ctx->n_mat)) {
-                        g2.solo_list = g2.fallback_list + cap;
-                        g2.solo_count = (unsigned int*)(state + RT_DEV_SOLO_AT);   // zeroed with the counters
-                        g2.solo_cap = (int)cap;
-                        double sw = (double)solo_work / (per_bounce > 1.0 ? per_bounce : 1.0);
-                        g2.solo_min_work = force_solo ? 0u : (unsigned int)(sw < 1.0 ? 1.0 : sw);
-                        if (force_solo) g2.heavy_min_work = 0xffffffffu;          // test hook: no pixel counts as steady
-                    }
                 }
-                // coop_kernel over the pixels the listed kernel hands over: its list and length live on the device
-                auto launch_solo = [&](hipStream_t st) -> hipError_t {
-                    if (!g2.solo_list) return hipSuccess;
-                    KernelArgs g3 = g2;
-                    g3.list = g2.solo_list; g3.list_count = g2.solo_cap; g3.list_count_dev = g2.solo_count;
-                    g3.queue = g2.solo_count + 1;
-                    g3.heavy_cap = 0; g3.solo_list = nullptr;
-                    return rt_launch_coop(g3, tg, st);
-                };
                 // Frames in flight (RT_FLAG_SEQUENCE): the listed kernels go onto the context's one stream (the direct
                 // kernel onto one of the device's shared streams, below; behind the listed kernels on this stream when
                 // those are off) -- the kernels of the other frames in flight run beside them.  HIP deals streams to
                 // hardware queues as they are created; a context that never needs a second stream never creates one, so
                 // N contexts in flight are N busy queues plus the shared ones.
                 static const int seq_streams = getenv("RT_SEQ_STREAMS") ? atoi(getenv("RT_SEQ_STREAMS")) : RT_SEQ_STREAMS_DEFAULT;
-                const bool sequence = g2.heavy_cap > 0 && !coop && !rays && (p->flags & RT_FLAG_SEQUENCE) != 0;
+                const bool sequence = g2.heavy_cap > 0 && !coop && (p->flags & RT_FLAG_SEQUENCE) != 0;
                 hipStream_t s2 = ctx->stream;
                 // (rt_render_rows_static creates nothing, streams included: its listed kernel runs in front of the direct one)
                 // Large scenes: the direct kernel (tens of ms) runs in front of coop_kernel on the same stream.  Side by
@@ -822,8 +785,6 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                 if (coop) {
                     if (n_listed < npix) { HIP_TRY(ctx, launch_direct(a, t, ctx->stream)); direct_done = true; }
                     HIP_TRY(ctx, rt_launch_coop(g2, tg, s2));
-                } else if (rays) {
-                    HIP_TRY(ctx, rt_launch_rays(g2, tg, s2));
                 } else if (sequence) {
                     static const int shared_n = std::min(RT_SEQ_DIRECT_MAX, getenv("RT_SEQ_DIRECT_STREAMS") ? atoi(getenv("RT_SEQ_DIRECT_STREAMS")) : RT_SEQ_DIRECT_STREAMS);
                     if (shared_n > 0 && s2 == ctx->stream && !no_alloc && ctx->counted && n_listed < npix) {
@@ -854,7 +815,6 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     g2.listed_mode = RT_MODE_ALL;
                     HIP_TRY(ctx, rt_launch_render(g2, tg, s2));
                     HIP_TRY(ctx, rt_launch_heavy(g2, tg, s2));
-                    HIP_TRY(ctx, launch_solo(s2));
                 } else if (g2.heavy_cap > 0) {
                     // the steady long pixels: first samples, hand-over, heavy kernel, resume kernel ...
                     g2.listed_mode = RT_MODE_STEADY;
@@ -865,7 +825,6 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     if (!ctx->stream3) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
                     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_list, 0));
                     HIP_TRY(ctx, rt_launch_render(g2, tg, ctx->stream3));
-                    HIP_TRY(ctx, launch_solo(ctx->stream3));
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_rest, ctx->stream3));
                     rest = true;
                 } else {

@@ -297,93 +297,6 @@ __device__ __noinline__ static void stream_turns(unsigned int* out, int turns)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The same generator as a stream kept in an LDS ring, for rays_kernel (rt_kernels.hip): one pixel's rand() sequence,
-// written out ahead of use by half a wave at a time, read at *guessed* positions by the lanes that trace the pixel's
-// rays side by side.  Stream word i: words 0..30 are the state srand() and the 310 discarded outputs leave, oldest
-// first; word 31 + n is draw n (output = word >> 1); word i = word i-3 + word i-31.  The ring holds the last RT_RING
-// words: word i sits in slot i % RT_RING.
-#ifndef RT_RING
-#define RT_RING 512
-#endif
-static_assert((RT_RING & (RT_RING - 1)) == 0 && RT_RING >= 128, "the ring's length is a power of two");
-
-// 16807^n mod (2^31 - 1): srand()'s 30 Lehmer steps (glibc random_r.c __srandom_r) as one multiplication
-// per word.  Schrage's form 16807*lo - 2836*hi (+ M if negative) is 16807*w mod M in [0, M) for every int w, negative
-// seeds included, so word n = (16807^n mod M) * (w mod M) mod M.
-__device__ static const unsigned int rt_lehmer_pow[31] = {
-    1u, 16807u, 282475249u, 1622650073u, 984943658u, 1144108930u, 470211272u, 101027544u, 1457850878u, 1458777923u,
-    2007237709u, 823564440u, 1115438165u, 1784484492u, 74243042u, 114807987u, 1137522503u, 1441282327u, 16531729u,
-    823378840u, 143542612u, 896544303u, 1474833169u, 1264817709u, 1998097157u, 1817129560u, 1131570933u, 197493099u,
-    1404280278u, 893351816u, 1505795335u };
-
-// word n (0..30) of srand(seed)'s table r[] (rand.h:7 -> glibc srandom_r)
-__device__ __forceinline__ unsigned int srand_word(unsigned int seed, int n)
-{
-    const unsigned int s = seed == 0u ? 1u : seed;
-    if (n == 0) return s;
-    const long long w = (long long)(int)s;
-    long long m = w % 2147483647ll;
-    if (m < 0) m += 2147483647ll;
-    unsigned long long x = (unsigned long long)rt_lehmer_pow[n] * (unsigned long long)m;      // < 2^62
-    x = (x >> 31) + (x & 2147483647ull);                                                       // < 2^32
-    x = (x >> 31) + (x & 2147483647ull);                                                       // <= 2^31
-    if (x >= 2147483647ull) x -= 2147483647ull;
-    return (unsigned int)x;
-}
-
-// One turn of the generator by half a wave: lane n (0..30 of its half) holds word base + n and receives word
-// base + 31 + n.  With a[n] the old words, new[n] = a[n] + (n >= 3 ? new[n-3] : a[28+n]): per residue class of n mod 3
-// an inclusive prefix sum (four doubling steps of stride 3) plus the class's seed a[28 + n%3].  Every lane of the wave
-// must call it (cross-lane reads); lane 31 of a half carries nothing.
-__device__ __forceinline__ unsigned int stream_turn_half(unsigned int a)
-{
-    const int lane = (int)(threadIdx.x & 63), n = lane & 31, half = lane & 32;
-    unsigned int x = a;
-#pragma unroll
-    for (int s = 3; s <= 24; s <<= 1) {
-        const unsigned int y = (unsigned int)__shfl((int)x, half + (n >= s ? n - s : n));
-        if (n >= s) x += y;
-    }
-    const int c = n - 3 * (n / 3);
-    return x + (unsigned int)__shfl((int)a, half + 28 + c);
-}
-
-struct RngRing {
-    unsigned int* ring;     // the pixel's ring (LDS)
-    unsigned int w;         // stream word of the next draw
-    unsigned int hi;        // words [.., hi) exist
-    unsigned int clobber;   // writing word `clobber` or a later one overwrites words other lanes may be reading
-    bool owner;             // this lane's first draw is known to be the right one: it may extend the stream
-    bool overflow;          // (not the owner) drew past `hi`: the values were not the generator's
-    bool extended;          // (owner) wrote past `clobber`
-    bool seeded;
-    unsigned int ndraws;
-
-    __device__ __forceinline__ void start(unsigned int* r, unsigned int first_word, unsigned int have, unsigned int clobber_at, bool own)
-    {
-        ring = r; w = first_word; hi = have; clobber = clobber_at; owner = own;
-        overflow = false; extended = false; seeded = true; ndraws = 0;
-    }
-    __device__ __forceinline__ void do_seed() {}
-
-    __device__ __forceinline__ void next3(int& o0, int& o1, int& o2)
-    {
-        ndraws += 3;
-        if (w + 3u > hi) {
-            if (!owner) { overflow = true; w += 3u; o0 = o1 = o2 = 0; return; }
-            while (hi < w + 3u) {                                   // the words they depend on all exist
-                ring[hi & (RT_RING - 1)] = ring[(hi - 3u) & (RT_RING - 1)] + ring[(hi - 31u) & (RT_RING - 1)];
-                if (hi >= clobber) extended = true;
-                ++hi;
-            }
-        }
-        const unsigned int v0 = ring[w & (RT_RING - 1)], v1 = ring[(w + 1u) & (RT_RING - 1)], v2 = ring[(w + 2u) & (RT_RING - 1)];
-        w += 3u;
-        o0 = (int)(v0 >> 1); o1 = (int)(v1 >> 1); o2 = (int)(v2 >> 1);
-    }
-};
-
 // randomUnit() = (float)rand() / (float)RAND_MAX, (float)RAND_MAX == 2^31 (rand.h:9)
 __device__ __forceinline__ float rand_unit(int r) { return (float)r * 4.656612873077392578125e-10f; }
 

@@ -51,6 +51,10 @@ constexpr int BLOCK = 256;
 #ifndef RT_LISTED_WAVES
 #define RT_LISTED_WAVES 4
 #endif
+// the listed render_kernel's per-wave candidate lists for the primary segment (listed_wave_lists)
+#ifndef RT_LISTED_LISTS
+#define RT_LISTED_LISTS 1
+#endif
 // coop_kernel: the path state in scalar registers (rt_device.hpp uni()).  Off: measured on C4
 // it takes the register spills from 43 to 16 and the kernel's HBM traffic from 194 to 94 GB per frame, at 3 % more
 // instructions and 846 instead of 833 ms -- the spills are not what the frame waits for.
@@ -140,7 +144,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
             if (COUNT) ++cnt.closest;
             float dist;
             int bi;
-            const bool listed_query = BATCH == RT_COOP && primary && sc.cl_nprim >= 0;      // coop_kernel's candidate lists
+            const bool listed_query = primary && sc.cl_nprim >= 0;      // a wave's (coop_kernel: a pixel's) candidate lists
             if (listed_query)                                  bi = closest_hit_ldslist<HAS_NONSPHERE>(sc, sc.cl_prim, sc.cl_nprim, ro, rd, dist);
             else if (!HAS_NONSPHERE && primary && BATCH != RT_COOP) bi = closest_hit_primary<COUNT>(sc, rd, dist, cnt);
             else                                               bi = closest_hit<HAS_NONSPHERE, COUNT, BATCH>(sc, ro, rd, dist, cnt);
@@ -368,8 +372,7 @@ __device__ __forceinline__ PixelId listed_pixel(const KernelArgs& a)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     PixelId p;
-    const unsigned int n = a.list_count_dev ? *a.list_count_dev : (unsigned int)a.list_count;
-    p.active = (unsigned int)i < n;
+    p.active = (unsigned int)i < (unsigned int)a.list_count;
     const unsigned int o = p.active ? a.list[i] : 0u;
     p.x = (int)(o % (unsigned int)a.width);
     p.r = (int)(o / (unsigned int)a.width);
@@ -505,17 +508,9 @@ __device__ __forceinline__ bool heavy_handover(const KernelArgs& a, RNG& rng, un
 // (x, y) of the frame = column x of packed output row r.
 // LDS_RNG: the generator's 31 words live in LDS at rng_lds (slot-major) instead of in scratch.  HEAVY: pixels whose
 // first sample shows a long path are handed to heavy_kernel.
-__device__ __forceinline__ bool solo_handover(const KernelArgs& a, unsigned int pixel)
-{
-    const unsigned int k = atomicAdd(a.solo_count, 1u);
-    if (k >= (unsigned int)a.solo_cap) return false;           // (the count may run past the list: those pixels stay where they are)
-    a.solo_list[k] = pixel;
-    return true;
-}
-
 template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, bool LDS_RNG, int BATCH, bool HEAVY, int STRIDE = BLOCK>
 __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds& sc, float* dirs, unsigned int* rng_lds,
-                                             int x, int y, int r, Counters& cnt, bool writer = true)
+                                             int x, int y, int r, Counters& cnt, bool writer = true, bool dirs_ready = false)
 {
     const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
     typedef RngT<LDS_RNG ? STRIDE : 1> RNG;
@@ -525,7 +520,7 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
 
     // AntiAliasing is called with the same (u, v) for every sample (main.cpp:312), so the four primary directions
     // are per-pixel constants: computed once, parked in LDS (12 words per thread, word j of thread t at [j*BLOCK + t]).
-    primary_directions<STRIDE>(a, dirs, x, y);
+    if (!dirs_ready) primary_directions<STRIDE>(a, dirs, x, y);
 
     const size_t o = (size_t)x + (size_t)r * a.width;
     v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0);
@@ -557,15 +552,9 @@ __device__ __forceinline__ void render_pixel(const KernelArgs& a, const SceneLds
                 // (the test hook, threshold 0, also hands over pixels whose counts differ: the re-guess path)
                 const bool eligible = guess > 0 && (agree >= RT_HEAVY_AGREE || a.heavy_min_work == 0)
                     && (unsigned long long)guess * (unsigned int)(a.samples - RT_HEAVY_PROBE) >= (unsigned long long)a.heavy_min_work;
-                // Long pixels whose counts differ stay serial, and a lane that walks one holds its wave (and the frame)
-                // for the pixel's whole chain: they leave after these four samples for a wave of their own --
-                // coop_kernel over a.solo_list renders them from their first sample (solo_* in rt_launch.h).
-                const unsigned long long est = ((unsigned long long)c0 + c1 + c2 + c3) * (unsigned int)(a.samples - RT_HEAVY_PROBE) / RT_HEAVY_PROBE;
-                const bool solo = !eligible && a.solo_list != nullptr && est >= (unsigned long long)a.solo_min_work;
-                if (a.listed_mode == RT_MODE_REST) { if (eligible) return; if (solo && solo_handover(a, (unsigned int)o)) return; }
+                if (a.listed_mode == RT_MODE_REST) { if (eligible) return; }
                 else if (eligible) { if (heavy_handover(a, rng, (unsigned int)o, guess, acc_color, acc_em, acc_st)) return; }
                 else if (a.listed_mode == RT_MODE_STEADY) return;
-                else if (solo && solo_handover(a, (unsigned int)o)) return;
             }
         }
     }
@@ -902,6 +891,68 @@ __global__ __launch_bounds__(BLOCK, (HAS_NONSPHERE || EMISSION) ? 1 : RT_DIRECT_
         a.emission[o] = make_float4(acc_em.x / n, acc_em.y / n, acc_em.z / n, acc_st / n);
 }
 
+// The listed kernel's waves: candidate lists for the primary segment of every ray, as in the direct kernel (rt_device.hpp
+// "wave-level candidate lists") -- a listed pixel's four primary rays and the shadow rays of their hit points are the same
+// for every sample too, only what follows the first hit hangs on the numbers drawn.  One pass over the scene per wave
+// (all 64 lanes alive: lanes past the end of the pixel list come along with nothing to offer), the hittables some primary
+// ray of the wave hits / that occlude some light from some primary hit point in two short lists in LDS, in scene order;
+// trace_path's first query and its shading then walk those instead of the scene.  Scenes of at most LISTED_LIST
+// hittables (larger ones: no lists, every query over the scene).
+constexpr int LISTED_LIST = 32;
+
+template <bool HAS_NONSPHERE>
+__device__ __forceinline__ void listed_wave_lists(const KernelArgs& a, SceneLds& sc, const float* dirs, bool mine,
+                                                  unsigned short* lp, unsigned short* lo)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
+    int nprim = 0, noccl = 0;
+    for (int i = 0; i < sc.n_hit; ++i) {
+        const float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
+        bool any = false;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+            const float fa = 4.0f * dot(rd, rd);
+            v3 inv = mk(0, 0, 0);
+            if (HAS_NONSPHERE) inv = mk(rt_rcp(rd.x), rt_rcp(rd.y), rt_rcp(rd.z));
+            float t;
+            any = any || hittable_hit<HAS_NONSPHERE>(r0, r1, origin, rd, fa, inv, t);
+        }
+        if (__ballot(any && mine) != 0ull) { if (lane == 0) lp[nprim] = (unsigned short)i; ++nprim; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned int listed = 0u;                                  // hittables on the occluder list, one bit each
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+        float dist;
+        const int bi = closest_hit_ldslist<HAS_NONSPHERE>(sc, lp, nprim, origin, rd, dist);
+        const bool hit = mine && bi >= 0;
+        if (__ballot(hit) == 0ull) continue;
+        v3 pos = mk(0, 0, 0);
+        if (hit) { const Hit h = hit_record<!HAS_NONSPHERE>(sc, bi, origin, rd, dist); pos = h.position + h.normal * 0.005f; }
+        for (int j = 0; j < sc.n_lights; ++j) {
+            int type; float ldist;
+            const v3 l = light_direction(sc, j, pos, type, ldist);
+            const float fa = 4.0f * dot(l, l);
+            v3 inv = mk(0, 0, 0);
+            if (HAS_NONSPHERE) inv = mk(rt_rcp(l.x), rt_rcp(l.y), rt_rcp(l.z));
+            for (int i = 0; i < sc.n_hit; ++i) {
+                if ((listed >> i) & 1u) continue;
+                const float4 r0 = sc.urec(2 * i), r1 = sc.urec(2 * i + 1);
+                const bool o = hit && ((type == L_DIR) ? occluder_hit<HAS_NONSPHERE, false, false>(r0, r1, pos, l, fa, inv, 0.0f)
+                                                       : occluder_hit<HAS_NONSPHERE, false, true>(r0, r1, pos, l, fa, inv, ldist));
+                if (__ballot(o) != 0ull) listed |= 1u << i;
+            }
+        }
+    }
+    for (int i = 0; i < sc.n_hit; ++i)                          // in scene order
+        if ((listed >> i) & 1u) { if (lane == 0) lo[noccl] = (unsigned short)i; ++noccl; }
+    __builtin_amdgcn_wave_barrier();
+    sc.cl_prim = lp; sc.cl_nprim = nprim; sc.cl_occl = lo; sc.cl_noccl = noccl;
+}
+
 // render_kernel: the general per-pixel driver.  LISTED: over the pixel list built by classify / scatter, at raised
 // wave priority (these are the long pixels; the direct kernel's waves fill in around them).  Otherwise over 16x16
 // tiles of every pixel (tallying builds).
@@ -919,8 +970,18 @@ __global__ __launch_bounds__(BLOCK, LISTED ? RT_LISTED_WAVES : RT_MIN_WAVES) voi
     // the listed kernel has few, long waves: it trades LDS and registers for shorter dependent chains
     constexpr int BATCH = LISTED ? RT_LISTED_BATCH : 1;
     unsigned int* rng_lds = (unsigned int*)(lds_free + 12 * BLOCK) + threadIdx.x;
+    bool dirs_ready = false;
+#if RT_LISTED_LISTS
+    if (LISTED && !COUNT && PRUNE && sc.n_hit <= LISTED_LIST) {
+        // (the lists sit behind the per-thread words: 2 x LISTED_LIST entries per wave; rt_launch_lds_bytes has the room)
+        unsigned short* lp = (unsigned short*)(lds_free + 12 * BLOCK + (LDS_RNG ? 32 * BLOCK : 0)) + (threadIdx.x >> 6) * (2 * LISTED_LIST);
+        primary_directions(a, lds_free + threadIdx.x, p.x, p.y);
+        dirs_ready = true;
+        listed_wave_lists<HAS_NONSPHERE>(a, sc, lds_free + threadIdx.x, p.active, lp, lp + LISTED_LIST);
+    }
+#endif
     if (p.active)
-        render_pixel<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, LDS_RNG, BATCH, LISTED>(a, sc, lds_free + threadIdx.x, rng_lds, p.x, p.y, p.r, cnt);
+        render_pixel<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, LDS_RNG, BATCH, LISTED>(a, sc, lds_free + threadIdx.x, rng_lds, p.x, p.y, p.r, cnt, true, dirs_ready);
     if (COUNT && p.active) flush_counters(a, cnt);
 }
 
@@ -1073,10 +1134,7 @@ __global__ __launch_bounds__(COOP_WAVES * 64, RT_COOP_MIN_WAVES) void coop_kerne
     // done: every wave therefore takes pixels from a queue (a counter over the list) until the list is used up, and
     // the grid is only as large as fits the GPU at once (rt_launch_coop).
     // (a wave takes at most list_count pixels: the bound is never reached, and no wave can spin for ever)
-    // (the list's length may live on the device -- pixels handed over by the listed kernel in front of this launch --
-    // and may have run past the list's capacity)
-    unsigned int n_list = (unsigned int)a.list_count;
-    if (a.list_count_dev) { const unsigned int d = *a.list_count_dev; n_list = d < n_list ? d : n_list; }
+    const unsigned int n_list = (unsigned int)a.list_count;
     for (unsigned int turn = 0; turn <= n_list; ++turn) {
     unsigned int i = 0;
     if (lane == 0) i = atomicAdd(a.queue, 1u);
@@ -1180,241 +1238,6 @@ __global__ __launch_bounds__(COOP_WAVES * 64, RT_COOP_MIN_WAVES) void coop_kerne
 
     render_pixel<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, true, RT_COOP, false, COOP_WAVES>(
         a, sc, dirs, rng_lds, x, y, r, cnt, lane == 0);
-    }
-}
-
-// rays_kernel: listed pixels of small scenes, one lane per *ray*.
-//
-// A pixel's rays are serial only through the generator: one srand() per pixel (main.cpp:304) feeds all of its
-// 4 * samples rays in order, so ray q can only start where ray q-1 stopped drawing.  Everything else about a ray is a
-// function of its primary direction (q % 4: AntiAliasing is called with the same u, v for every sample, main.cpp:312)
-// and of the position in the pixel's rand() sequence at which it starts.  So a group of RAYS_GROUP lanes takes one
-// pixel, its lanes trace the pixel's next RAYS_GROUP rays side by side, each from a *guessed* position: the pixel's
-// sequence is written out ahead of use into an LDS ring (rt_device.hpp RngRing) and the guess for ray q is the start of
-// the first unsettled ray plus what the rays in between are expected to draw (per direction: what the last rays in that
-// direction drew).  Afterwards the group checks the guesses from the front: the first ray's start is always right; a
-// ray's start is right if all rays before it drew what was guessed for them.  Rays up to and including the first one
-// that drew something else stand ("settle"): their results are added to the pixel's sums in ray order (renderer.h:169-
-// 198, main.cpp:313-315), the next ray's true start is then known, and the rays behind trace again next round.  A round
-// costs the longest of its rays and settles at least one; where the draw counts repeat (a path whose shape does not
-// hang on the numbers drawn: glass, mirrors; or a rough surface that mostly sees the ground and the sky) it settles all
-// RAYS_GROUP.  No lane carries a pixel's whole serial chain any more, and a wave's four groups take their pixels from a
-// queue, so no wave waits for one long pixel.
-//
-// Every settled ray was traced from its true position in the sequence with the reference's operations, and the sums
-// are formed in the reference's order: same bytes as the serial loop.  Rays traced from a wrong guess only cost time
-// (whatever numbers they see, a path is bounded by its multiplier and depth, renderer.h:30,68).
-//
-// The ring holds RT_RING words.  Before each round half-waves extend it as far as it goes without overwriting words from
-// the first unsettled ray's start on (stream_turn_half: 31 words per turn), which leaves that ray >= 140 bounces
-// of numbers.  A first ray that needs more (a deep tree of a reflect-and-refract material) extends the sequence itself,
-// word by word, over the oldest words; the other rays of the round may then have read overwritten words and are all
-// traced again (`extended`).  A later ray that runs out of numbers is traced again too (`overflow`).
-constexpr int RAYS_GROUP = 16;
-constexpr int RAYS_WAVES = 4;
-constexpr int RAYS_GROUPS = RAYS_WAVES * 64 / RAYS_GROUP;      // pixels a workgroup has under way
-constexpr int RAYS_GROUP_WORDS = RT_RING + 16;                 // a group's LDS: the ring, 12 direction words, padding
-#ifndef RT_RAYS_MIN_WAVES
-#define RT_RAYS_MIN_WAVES 4
-#endif
-
-__device__ __forceinline__ unsigned int sel4(unsigned int v0, unsigned int v1, unsigned int v2, unsigned int v3, int i)
-{
-    return i == 0 ? v0 : i == 1 ? v1 : i == 2 ? v2 : v3;
-}
-__device__ __forceinline__ void set4(unsigned int& v0, unsigned int& v1, unsigned int& v2, unsigned int& v3, int i, unsigned int x)
-{
-    if (i == 0) v0 = x; else if (i == 1) v1 = x; else if (i == 2) v2 = x; else v3 = x;
-}
-
-template <bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int MAXSP, int MAXPEND>
-__global__ __launch_bounds__(RAYS_WAVES * 64, RT_RAYS_MIN_WAVES) void rays_kernel(KernelArgs a)
-{
-    extern __shared__ float4 lds[];
-    SceneLds sc;
-    float* lds_free;
-    stage_scene(a, lds, sc, lds_free);
-    __builtin_amdgcn_s_setprio(3);
-
-    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-    const int k = lane & (RAYS_GROUP - 1);                  // place in the group
-    const int gbase = lane & ~(RAYS_GROUP - 1);             // the group's first lane
-    unsigned int* const wave_lds = (unsigned int*)lds_free + (size_t)wave * 4 * RAYS_GROUP_WORDS;
-    unsigned int* const ring = wave_lds + (size_t)(lane >> 4) * RAYS_GROUP_WORDS;
-    float* const dirs = (float*)(ring + RT_RING);
-    const int n31 = lane & 31;                              // place in the half-wave that writes streams
-    const int nrays = 4 * a.samples;
-    const unsigned int count = (unsigned int)a.list_count;
-    const v3 origin = mk(a.cam[0], a.cam[1], a.cam[2]);
-    Counters cnt = { 0, 0, 0, 0, 0 };
-
-    // the group's state, the same in all of its lanes
-    bool have = false, done = false, probe = false;
-    unsigned int o = 0, seed = 0;
-    int first = 0;                                          // the pixel's first unsettled ray
-    unsigned int lo_w = 31u, hi = 31u;                      // stream word at which ray `first` starts; words below hi exist
-    unsigned int g0 = 3u, g1 = 3u, g2 = 3u, g3 = 3u;        // words a ray in direction d is expected to draw
-    unsigned int l0 = 3u, l1 = 3u, l2 = 3u, l3 = 3u;        // words the last settled ray in direction d drew
-    v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0), res_color = mk(0, 0, 0), res_em = mk(0, 0, 0);
-    float acc_st = 0.0f, res_st = 0.0f;
-
-    // Every round settles at least one ray of every pixel under way and the queue is finite: the bound is never reached.
-    const unsigned long long bound = (unsigned long long)count * (unsigned long long)(nrays + 1) + 4ull;
-    for (unsigned long long round = 0; round < bound; ++round) {
-        // ---- groups without a pixel take the next one from the queue
-        bool fresh = false;
-        if (!have && !done) {
-            unsigned int i = 0;
-            if (k == 0) i = atomicAdd(a.queue, 1u);
-            i = (unsigned int)__shfl((int)i, gbase);
-            if (i < count) {
-                o = a.list[i];
-                const int x = (int)(o % (unsigned int)a.width), r = (int)(o / (unsigned int)a.width);
-                const int y = frame_row(a, r);
-                seed = a.seed_base + (unsigned int)(x + y * a.width);                    // rand.h:7, main.cpp:304
-                first = 0; lo_w = 31u; hi = 31u;
-                g0 = g1 = g2 = g3 = 3u; l0 = l1 = l2 = l3 = 3u;
-                acc_color = mk(0, 0, 0); acc_em = mk(0, 0, 0); res_color = mk(0, 0, 0); res_em = mk(0, 0, 0);
-                acc_st = 0.0f; res_st = 0.0f;
-                have = true; fresh = true; probe = true;
-                if (k < 4) {                                                             // renderer.h:140,167-191 over main.cpp:301-307
-                    Camera cam;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) cam.pos[j] = a.cam[j];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) { cam.ip[j] = a.cam[3 + j]; cam.iv[j] = a.cam[19 + j]; }
-                    const float u = ((float)x / (float)a.width) * 2.0f - 1.0f;
-                    const float v = -(((float)y / (float)a.height) * 2.0f - 1.0f);
-                    const float offX = 0.5f / a.width, offY = 0.5f / a.height;
-                    const v3 dd = uv_to_direction(cam, (k & 1) ? u + offX : u - offX, (k & 2) ? v + offY : v - offY);
-                    dirs[3 * k + 0] = dd.x; dirs[3 * k + 1] = dd.y; dirs[3 * k + 2] = dd.z;
-                }
-            } else {
-                done = true;
-            }
-        }
-        if (__ballot(have) == 0ull) break;
-
-        // ---- streams.  Half-wave h writes for groups 2h and 2h + 1, one after the other; lane n of the half holds word
-        // base + n of a run of 31.
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            const int sl = (lane & 32) + pass * RAYS_GROUP;                               // a lane of the served group
-            unsigned int* const sring = wave_lds + (size_t)(sl >> 4) * RAYS_GROUP_WORDS;
-            const bool s_have = __shfl((int)have, sl) != 0, s_fresh = __shfl((int)fresh, sl) != 0;
-            const unsigned int s_seed = (unsigned int)__shfl((int)seed, sl);
-            const unsigned int s_lo = (unsigned int)__shfl((int)lo_w, sl), s_hi = (unsigned int)__shfl((int)hi, sl);
-            if (__ballot(s_fresh) != 0ull) {
-                // srand(seed): words r[3..30], r[0..2] are the stream's first 31 words, oldest first; then the 310
-                // discarded outputs, ten turns (glibc srandom_r)
-                unsigned int wv = 0u;
-                if (n31 < 31) wv = srand_word(s_seed, n31 + 3 >= 31 ? n31 + 3 - 31 : n31 + 3);
-#pragma unroll 1
-                for (int t = 0; t < 10; ++t) wv = stream_turn_half(wv);
-                if (s_fresh && n31 < 31) sring[n31] = wv;                                 // words 0..30; draw 0 is word 31
-            }
-            __builtin_amdgcn_wave_barrier();
-            // as many turns as fit without overwriting words from s_lo - 31 on
-            const int turns = s_have ? (int)((s_lo - 31u + (unsigned int)RT_RING - s_hi) / 31u) : 0;
-            const int other = __shfl(turns, lane ^ 32);
-            const int tmax = __builtin_amdgcn_readfirstlane(turns > other ? turns : other);
-            unsigned int wv = 0u;
-            if (n31 < 31 && turns > 0) wv = sring[(s_hi - 31u + (unsigned int)n31) & (RT_RING - 1)];
-#pragma unroll 1
-            for (int t = 0; t < tmax; ++t) {
-                const unsigned int nv = stream_turn_half(wv);
-                if (t < turns) {
-                    wv = nv;
-                    if (n31 < 31) sring[(s_hi + 31u * (unsigned int)t + (unsigned int)n31) & (RT_RING - 1)] = wv;
-                }
-            }
-        }
-        if (have) hi += 31u * ((lo_w - 31u + (unsigned int)RT_RING - hi) / 31u);
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- trace: lane k takes ray first + k from its guessed position
-        const int q = first + k, d = q & 3, d0 = first & 3;
-        const bool active = have && q < nrays;
-        unsigned int pre = (unsigned int)(k >> 2) * (g0 + g1 + g2 + g3);
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (j < (k & 3)) pre += sel4(g0, g1, g2, g3, (d0 + j) & 3);
-        const unsigned int my_guess = sel4(g0, g1, g2, g3, d);
-        const unsigned int start = lo_w + pre;
-        RngRing rng;
-        rng.start(ring, start, hi, lo_w + (unsigned int)RT_RING, k == 0);
-        PathOut p;
-        p.color = mk(0, 0, 0); p.emission = mk(0, 0, 0); p.strength = 0.0f; p.maxDepth = 1;
-        if (active) {
-            const v3 dir = mk(dirs[3 * d + 0], dirs[3 * d + 1], dirs[3 * d + 2]);
-            p = trace_path<EMISSION, MIXED, HAS_NONSPHERE, false, true, MAXSP, MAXPEND, RngRing, RT_LISTED_BATCH>(sc, rng, origin, dir, a.max_depth, cnt, a.fault);
-        }
-        v3 pc = p.color;                                                                 // renderer.h:169
-        if (p.maxDepth != 1) { const float md = (float)p.maxDepth; pc = mk(pc.x / md, pc.y / md, pc.z / md); }
-        const unsigned int drew = rng.ndraws;
-
-        // ---- which rays stand
-        const bool usable = active && !rng.overflow;
-        const unsigned int m_usable = (unsigned int)(__ballot(usable) >> gbase) & 0xFFFFu;
-        const unsigned int m_exact = (unsigned int)(__ballot(usable && drew == my_guess) >> gbase) & 0xFFFFu;
-        const int jm = __builtin_ctz(~m_exact | 0x10000u);                               // first ray that drew something else
-        int settled = jm + (int)((m_usable >> jm) & 1u);                                 // (bit 16 is clear)
-        if (__shfl((int)rng.extended, gbase) != 0) settled = 1;
-        if (!have) settled = 0;
-        const unsigned int new_hi = (unsigned int)__shfl((int)rng.hi, gbase);            // the first ray may have extended it
-        const unsigned int new_lo = (unsigned int)__shfl((int)(start + drew), gbase + (settled > 0 ? settled - 1 : 0));
-
-        // ---- their results, in ray order (renderer.h:167-198, main.cpp:313-315)
-        int smax = __builtin_amdgcn_readlane(settled, 0);
-        { const int s1 = __builtin_amdgcn_readlane(settled, 16), s2 = __builtin_amdgcn_readlane(settled, 32), s3 = __builtin_amdgcn_readlane(settled, 48);
-          smax = smax > s1 ? smax : s1; smax = smax > s2 ? smax : s2; smax = smax > s3 ? smax : s3; }
-#pragma unroll 1
-        for (int j = 0; j < smax; ++j) {
-            const int src = gbase + j;
-            const float cx = __shfl(pc.x, src), cy = __shfl(pc.y, src), cz = __shfl(pc.z, src);
-            const unsigned int cj = (unsigned int)__shfl((int)drew, src);
-            float ex = 0.0f, ey = 0.0f, ez = 0.0f, es = 0.0f;
-            if (EMISSION) { ex = __shfl(p.emission.x, src); ey = __shfl(p.emission.y, src); ez = __shfl(p.emission.z, src); es = __shfl(p.strength, src); }
-            if (j < settled) {
-                const int dj = (first + j) & 3;
-                res_color = res_color + mk(cx, cy, cz);
-                if (EMISSION) {
-                    res_em = res_em + mk(ex, ey, ez);
-                    res_st = (dj == 0) ? es : gmax(res_st, es);                          // renderer.h:171,179,187,195
-                }
-                if (dj == 3) {                                                           // renderer.h:197-198, main.cpp:313-315
-                    res_color = res_color * 0.25f;
-                    acc_color = acc_color + mk(clamp01(res_color.x), clamp01(res_color.y), clamp01(res_color.z));
-                    res_color = mk(0, 0, 0);
-                    if (EMISSION) {
-                        res_em = res_em * 0.25f;
-                        acc_em = acc_em + mk(clamp01(res_em.x), clamp01(res_em.y), clamp01(res_em.z));
-                        acc_st += res_st;
-                        res_em = mk(0, 0, 0); res_st = 0.0f;
-                    }
-                }
-                // what to expect of the next rays in this direction: a count seen twice in a row
-                if (cj == sel4(l0, l1, l2, l3, dj)) set4(g0, g1, g2, g3, dj, cj);
-                set4(l0, l1, l2, l3, dj, cj);
-            }
-        }
-        if (probe) {
-            // a pixel's first round: what the first ray in each direction drew is the first guess for that direction, even
-            // if that ray started at a wrong place (a path that does not hang on the numbers draws the same count anyway)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned int cj = (unsigned int)__shfl((int)drew, gbase + j);
-                if (have && ((m_usable >> j) & 1u)) { set4(g0, g1, g2, g3, j, cj); set4(l0, l1, l2, l3, j, cj); }
-            }
-            probe = false;
-        }
-        if (have) {
-            first += settled; lo_w = new_lo; hi = new_hi;
-            if (first >= nrays) {
-                if (k == 0) store_pixel<EMISSION>(a, (size_t)o, acc_color, acc_em, acc_st);
-                have = false;
-            }
-        }
     }
 }
 
@@ -1670,7 +1493,8 @@ hipError_t RT_LAUNCH_DIRECT(const KernelArgs& a, const LaunchTraits& t, hipStrea
 size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat)
 {
     size_t nm = (size_t)((10 * n_mat + 3) & ~3);
-    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)12 * BLOCK * 4 + 16;
+    // (+ 512 bytes: the listed kernel's per-wave candidate lists, 4 waves x 2 x 32 entries)
+    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)12 * BLOCK * 4 + 16 + 512;
 }
 
 // the listed render_kernel also keeps the generators there: 31 words per thread
@@ -1751,54 +1575,6 @@ hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream
         if (e != hipSuccess) return e;                                                                                    \
         return t.deep ? launch_with_lds(resume_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, rblocks, lds, stream)             \
                       : launch_with_lds(resume_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, rblocks, lds, stream); }
-    RT_ALL_VARIANTS(RT_DISPATCH)
-#undef RT_DISPATCH
-    return hipErrorInvalidValue;
-}
-
-static size_t rays_lds_bytes(int n_hit, int n_lights, int n_mat)
-{
-    size_t nm = (size_t)((10 * n_mat + 3) & ~3);
-    return (size_t)n_hit * 32 + (size_t)n_lights * 16 + nm * 4 + (size_t)RAYS_GROUPS * RAYS_GROUP_WORDS * 4 + 16;
-}
-
-bool rt_launch_rays_fits(int n_hit, int n_lights, int n_mat)
-{
-    return rays_lds_bytes(n_hit, n_lights, n_mat) <= 160 * 1024;
-}
-
-template <class K>
-static hipError_t launch_rays(K k, const KernelArgs& a, size_t lds_bytes, hipStream_t stream)
-{
-    int blocks = (a.list_count + RAYS_GROUPS - 1) / RAYS_GROUPS;
-    if (blocks <= 0) return hipSuccess;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    // as many workgroups as are resident at once: their groups take pixels from the queue until it is empty
-    int per_cu = 0, dev = 0, cus = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, RAYS_WAVES * 64, lds_bytes);
-    if (e == hipSuccess) e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return e;
-    if (const char* dbg = getenv("RT_DEBUG_COOP")) {
-        fprintf(stderr, "[rt] coop launch: lds %zu B, %d workgroups of %d waves per CU by the occupancy query, %d CUs\n", lds_bytes, per_cu, COOP_WAVES, cus);
-        if (atoi(dbg) > 1) per_cu = atoi(dbg);
-    }
-    const int resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-    if (blocks > resident) blocks = resident;
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(RAYS_WAVES * 64), lds_bytes, stream, a);
-    return hipGetLastError();
-}
-
-// rays_kernel over the pixel list: a lane per ray, 16 lanes per pixel.
-hipError_t rt_launch_rays(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
-{
-    const size_t lds = rays_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
-#define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N)                          \
-        return t.deep ? launch_rays(rays_kernel<E, M, N, RT_STACK_DEEP, RT_PEND_DEEP>, a, lds, stream)         \
-                      : launch_rays(rays_kernel<E, M, N, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, lds, stream);
     RT_ALL_VARIANTS(RT_DISPATCH)
 #undef RT_DISPATCH
     return hipErrorInvalidValue;

@@ -46,7 +46,6 @@ struct KernelArgs {
     unsigned int* hist;          // RT_MAX_KEYS pixel counts per key
     const unsigned int* list;    // pixel list of the listed render_kernel (indices into the packed output)
     int list_count;
-    const unsigned int* list_count_dev;  // if not null: the list length lives on the device (list_count = capacity)
     // sample-parallel pixels (listed render_kernel -> heavy_kernel); heavy_cap == 0 switches the hand-over off
     unsigned int* heavy_count;   // pixels handed over (may run past heavy_cap: those were not handed over)
     unsigned int* heavy_rec;     // heavy_cap x RT_HEAVY_REC_WORDS (heavy_handover in rt_kernels.hip lists the fields)
@@ -58,13 +57,8 @@ struct KernelArgs {
     unsigned int* fallback_count;// pixels heavy_kernel gave up on ...
     unsigned int* fallback_list; // ... their record indices, for resume_kernel (heavy_cap entries)
     int listed_mode;             // RT_MODE_*: which pixels of the list this launch of the listed kernel owns
-    // long pixels with unsteady draw counts (listed render_kernel -> coop_kernel, one wave per pixel); null: off
-    unsigned int* solo_list;     // solo_cap pixels (indices into the packed output)
-    unsigned int* solo_count;    // pixels handed over (may run past solo_cap: those were not)
-    int solo_cap;
     int coop_lds_stack;          // coop_kernel: colour frames of a wave's bounce stack that live in LDS (set by rt_launch_coop;
                                  // the stack's capacity or more: all of it, emission frames and pending steps included)
-    unsigned int solo_min_work;  // hand over when mean draws of the first four samples * (samples left) reaches this
 };
 
 struct LaunchTraits {
@@ -85,8 +79,6 @@ hipError_t rt_launch_direct(const KernelArgs& a, const LaunchTraits& t, hipStrea
 hipError_t rt_launch_direct_relaxed(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);   // rt_kernels_relaxed.hip
 bool rt_launch_heavy_fits(int n_hit, int n_lights, int n_mat);
 bool rt_launch_coop_fits(int n_hit, int n_lights, int n_mat);
-bool rt_launch_rays_fits(int n_hit, int n_lights, int n_mat);
-hipError_t rt_launch_rays(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_coop(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_heavy(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);
 hipError_t rt_launch_probe(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream);

@@ -85,7 +85,7 @@ while time.time() < t_end:
     seed = int(rs.choice([0, 1, 1000, 123456789, 2**31 - 1, 2**32 - 5, 2**40 + 17]))
     row0 = int(rs.randint(0, H))
     rows = int(rs.randint(1, H - row0 + 1))
-    flags = int(rs.choice([0, 0, 0, _abi.RT_FLAG_SINGLE_KERNEL, _abi.RT_FLAG_FORCE_SAMPLE_PARALLEL, _abi.RT_FLAG_FORCE_SOLO]))
+    flags = int(rs.choice([0, 0, 0, _abi.RT_FLAG_SINGLE_KERNEL, _abi.RT_FLAG_FORCE_SAMPLE_PARALLEL]))
     if rs.randint(3) == 0:
         flags |= _abi.RT_FLAG_SEQUENCE          # the route of frames in flight (one listed launch, serial pixels sorted by cost)
     want, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, seed, row0=row0, rows=rows, threads=15)

@@ -441,42 +441,24 @@ def test_sample_parallel_route_equals_serial(rt):
     ("cube", 96, 64, 6, 5),
     ("degenerate", 120, 72, 4, 64),
 ])
-def test_ray_parallel_route_gives_the_same_bytes(rt, name, W, H, samples, depth):
-    """RT_FLAG_RAYS_LISTED renders the bounce pixels of a small scene a lane per ray, each ray from a guessed place in the
-    pixel's rand() sequence, and keeps what the guesses got right (rays_kernel).  Same bytes as the oracle, with and
-    without the emission buffer, also combined with the sequence hint."""
+def test_listed_routes_give_the_same_bytes(rt, name, W, H, samples, depth):
+    """The bounce pixels' routes -- a frame on its own (two listed launches side by side, long steady pixels handed to the
+    sample-parallel kernels), a frame of a sequence (one launch, generators in scratch, the direct kernel on a shared
+    stream) and every bounce pixel forced down the sample-parallel route -- with the listed kernel's per-wave candidate
+    lists: same bytes as the oracle, with and without the emission buffer.  (The cases are round 2's for its ray-parallel
+    route, which round 3 removed.)"""
     from raytracer_amd import _abi
     sc = scenes.BUILTIN[name]()
     want_rgb, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, 31, threads=8)
     rt.upload_scene(sc)
     cam = ra.camera35f(sc, W, H)
-    for flags in (_abi.RT_FLAG_RAYS_LISTED, _abi.RT_FLAG_RAYS_LISTED | _abi.RT_FLAG_SEQUENCE, 0):
+    for flags in (0, _abi.RT_FLAG_SEQUENCE, _abi.RT_FLAG_FORCE_SAMPLE_PARALLEL):
         rgb = np.zeros((H, W, 3), np.uint8); em = np.zeros((H, W, 4), np.float32)
         rt.render_rows(cam, rt.params(W, H, samples, depth, 31, flags=flags), rgb, em)
         assert np.array_equal(rgb, want_rgb), flags
         assert np.array_equal(em.view(np.uint32), want_em.view(np.uint32)), flags
         rgb = np.zeros((H, W, 3), np.uint8)
         rt.render_rows(cam, rt.params(W, H, samples, depth, 31, flags=flags), rgb, None)
-        assert np.array_equal(rgb, want_rgb), (flags, "rgb only")
-
-
-@pytest.mark.parametrize("name,W,H,samples,depth", [("glass_mirror", 96, 54, 16, 12), ("default4", 128, 64, 9, 10), ("cube", 64, 48, 8, 6)])
-def test_solo_route_gives_the_same_bytes(rt, name, W, H, samples, depth):
-    """RT_FLAG_FORCE_SOLO: every bounce pixel leaves the listed kernel after its first four samples and is rendered by a
-    wave of its own (coop_kernel over the hand-over list, its bounce stack in LDS) -- the route of long pixels with
-    unsteady draw counts, off by default.  Same bytes as the oracle, alone and with the sequence hint."""
-    from raytracer_amd import _abi
-    sc = scenes.BUILTIN[name]()
-    want_rgb, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, 5, threads=8)
-    rt.upload_scene(sc)
-    cam = ra.camera35f(sc, W, H)
-    for flags in (_abi.RT_FLAG_FORCE_SOLO, _abi.RT_FLAG_FORCE_SOLO | _abi.RT_FLAG_SEQUENCE):
-        rgb = np.zeros((H, W, 3), np.uint8); em = np.zeros((H, W, 4), np.float32)
-        rt.render_rows(cam, rt.params(W, H, samples, depth, 5, flags=flags), rgb, em)
-        assert np.array_equal(rgb, want_rgb), flags
-        assert np.array_equal(em.view(np.uint32), want_em.view(np.uint32)), flags
-        rgb = np.zeros((H, W, 3), np.uint8)
-        rt.render_rows(cam, rt.params(W, H, samples, depth, 5, flags=flags), rgb, None)
         assert np.array_equal(rgb, want_rgb), (flags, "rgb only")
 
 

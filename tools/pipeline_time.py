@@ -19,6 +19,7 @@ from bench import WORKLOADS
 
 wl, frames = sys.argv[1], int(sys.argv[2])
 scene_name, W, H, samples, depth = WORKLOADS[wl]
+depth = int(os.environ.get("RT_DEPTH", depth))          # (0: no pixel bounces -- the direct kernel alone, no classification)
 scene = ra.scenes.BUILTIN[scene_name]()
 ranks = int(os.environ.get("RT_EMULATE_RANKS", "1"))
 cam = ra.camera35f(scene, W, H)
