@@ -258,6 +258,10 @@ const char* rt_strerror(int status);
  *   rt_debug_cull     : out[i] = 1 if the large-scene kernels would visit the cluster of hittable `index` for ray i,
  *                       0 if they would skip it -- which they may only when rt_debug_intersect says "no hit" for
  *                       every hittable of that cluster (no counterpart in the reference: the skip rule's own test)
+ *   rt_debug_cull_enter: enter[i] = the ray parameter at which ray i enters that cluster's box as the large-scene
+ *                       kernels' distance rule sees it (-FLT_MAX where the rule does not apply): a closest-hit query
+ *                       drops the cluster once its best distance b has enter > max(1.001 b, 0), which it may only when
+ *                       no hittable of the cluster is hit at a distance below b (src/hittables/hittablesList.h:27)
  *   rt_debug_exact_math: the kernels' short correctly-rounded sqrt, reciprocal and 1/sqrt sequences against the
  *                       compiler's IEEE sqrtf and division over all 2^32 float bit patterns; mismatches3[k] = inputs on
  *                       which sequence k differs (0, 0, 0 is the claim; the reference's sqrt / division are IEEE,
@@ -267,6 +271,7 @@ int rt_debug_rand(rt_ctx* ctx, const uint32_t* seeds, int32_t n_seeds, int32_t n
 int rt_debug_quantise(rt_ctx* ctx, const float* in, int32_t n, uint8_t* out);
 int rt_debug_intersect(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays, float* out8);
 int rt_debug_cull(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays, uint8_t* out);
+int rt_debug_cull_enter(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays, float* enter);
 
 #ifdef __cplusplus
 }

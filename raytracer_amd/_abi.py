@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_camera_init", "rt_render_rows", "rt_render_rows_static", "rt_render_tiles", "rt_probe_max_depth",
     "rt_deinterleave_bands", "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy", "rt_gather_rows", "rt_render_gather", "rt_last_rccl_error", "rt_comm_count", "rt_last_gather_ms", "rt_apply_glow",
     "rt_last_kernel_ms", "rt_last_device_ms", "rt_last_hip_error", "rt_strerror",
-    "rt_debug_rand", "rt_debug_quantise", "rt_debug_intersect", "rt_debug_cull", "rt_debug_exact_math",
+    "rt_debug_rand", "rt_debug_quantise", "rt_debug_intersect", "rt_debug_cull", "rt_debug_cull_enter", "rt_debug_exact_math",
 ]
 
 
@@ -109,6 +109,7 @@ def load():
     lib.rt_debug_quantise.argtypes = [vp, vp, i32, vp]
     lib.rt_debug_intersect.argtypes = [vp, i32, vp, i32, vp]
     lib.rt_debug_cull.argtypes = [vp, i32, vp, i32, vp]
+    lib.rt_debug_cull_enter.argtypes = [vp, i32, vp, i32, vp]
     lib.rt_debug_exact_math.argtypes = [vp, vp]
     _lib = lib
     return lib

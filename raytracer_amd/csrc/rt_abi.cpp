@@ -595,6 +595,25 @@ int rt_debug_cull(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays,
     return RT_OK;
 }
 
+int rt_debug_cull_enter(rt_ctx* ctx, int32_t index, const float* rays, int32_t n_rays, float* enter)
+{
+    if (!ctx || !rays || !enter || n_rays <= 0) return RT_ERR_INVALID_ARG;
+    if (!ctx->has_scene) return RT_ERR_NO_SCENE;
+    if (index < 0 || index >= ctx->n_hit) return RT_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return RT_ERR_NO_DEVICE;
+    float* d_rays = nullptr; float* d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_rays, sizeof(float) * 6 * (size_t)n_rays));
+    hipError_t e = hipMalloc((void**)&d_out, sizeof(float) * (size_t)n_rays);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, sizeof(float) * 6 * (size_t)n_rays, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = rt_launch_debug_cull_enter(ctx->d_clusters, ctx->d_slot_of, index, d_rays, n_rays, d_out, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(enter, d_out, sizeof(float) * (size_t)n_rays, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_rays); if (d_out) (void)hipFree(d_out);
+    HIP_TRY(ctx, e);
+    return RT_OK;
+}
+
 }  // extern "C"
 
 // rt_render_rows and rt_render_rows_static.  `no_alloc`: the call may not allocate -- its per-frame state and pixel

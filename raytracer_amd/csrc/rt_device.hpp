@@ -487,7 +487,12 @@ __device__ __forceinline__ float wave_extreme(float v)
 //     the computed tMin - tMax >= g - 3 u (2 D / |d_k| + g) > 0.  (b): min_i (t_exit_i + m / |d_i|) < 0, so for that
 //     i the computed t_exit_i, and with it tMax, is negative (|t_exit_i| > m / |d_i|: far from rounding to -0).
 //     Both need 1 / d_i finite and the products neither NaN nor infinite (cube.h's comparisons come out `true` on
-//     those): rounds with a cube in them are only skipped for rays with every |d_i| > 1e-12.
+//     those): rounds with a cube in them are only skipped for rays with every |d_i| > 1e-24 -- with D <= 1e12 no
+//     product then passes 1e36.  (The bounds above are ratios: they do not care how small a finite |d_i| is.  Round 2
+//     had 1e-12 here, and C4 paid for it: a ray refracted into a glass cube comes out of refract() along an axis but
+//     for components of 1e-12 .. 1e-13, is "hit" by its own cube at tMin = -0.01 (cube.h:28 takes tMin when the origin
+//     is inside), steps back and repeats until the multiplier runs out -- 66 closest-hit queries per such ray, a fifth
+//     of all closest-hit queries of the frame, every one of them scanning all 33 rounds.)
 //   Overflow and underflow would break these bounds (a NaN discriminant *is* a hit, sphere.h:22,32): nothing is skipped
 //   unless d.d is within [1e-6, 1e6] and D within [1e-6, 1e12] (NaNs fail that too).
 //   Planes and hittables with non-finite parameters make their round's box infinite: always visited.
@@ -506,7 +511,7 @@ __device__ __forceinline__ bool cluster_may_hit(float4 c, float4 h, v3 ro, v3 rd
     const float fx = fabsf(ox) + h.x, fy = fabsf(oy) + h.y, fz = fabsf(oz) + h.z;
     const float dd = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z, D2 = fx * fx + fy * fy + fz * fz;
     bool usable = dd >= 1e-6f && dd <= 1e6f && D2 >= 1e-12f && D2 <= 1e24f;
-    if (c.w != 0.0f) usable = usable && ax > 1e-12f && ay > 1e-12f && az > 1e-12f;
+    if (c.w != 0.0f) usable = usable && ax > 1e-24f && ay > 1e-24f && az > 1e-24f;
     if (!usable) return true;
     const float m = rt_sqrt(D2) * RT_CULL_MARGIN;
     const float Hx = h.x + m, Hy = h.y + m, Hz = h.z + m;
@@ -533,6 +538,65 @@ __device__ __forceinline__ unsigned long long cluster_mask(const SceneLds& sc, v
     return __ballot(visit);
 }
 
+// The same, in two parts: `near`, the rounds whose grown box holds the ray's origin -- scanned first: the hittable a
+// bounce ray leaves, its neighbours, the ground -- and `rest`; and for the rounds of `rest` where the ray enters lane k's
+// box (`enter`, the parameter t by slabs), so that a query can drop rounds it has no use for any more:
+//   closest hit: a round entered later than the best distance so far.  For rays with every |d_i| > 1e-24 and |d|^2
+//     within 1e-4 of 1 (`by_dist`; the others skip nothing this way) the t at which the ray enters the box grown by
+//     m = D / 100 (each product within 3 u of its value) is at least 0.9 m below the t of any point P of a member,
+//     all of which lie inside the box proper.  A member that is hit, is hit at such a P -- an origin inside a member is
+//     inside the box: a `near` round -- and its computed distance (sphere.h:26-27's root is t |d|^2 within 100 u D,
+//     cube.h:28's tMin is t within 3 u) is at least t (1 - 2e-4) - 1e-5 D > enter.  So enter > 1.001 best (0 for a
+//     negative best: the origin lies inside a cube, cube.h:28, and only hittables that hold the origin can beat it) puts
+//     every member's distance above `best`, and a hit with `distance >= best` is a `continue` in hittablesList.h:27;
+//   the point light's "something closer than the light": the same with the light's distance for `best`.
+struct ClusterRounds { unsigned long long near, rest; float enter; bool by_dist; };
+
+__device__ __forceinline__ bool ray_by_dist(v3 rd)
+{
+    const float dd = dot(rd, rd);
+    return dd >= 0.9999f && dd <= 1.0001f && fabsf(rd.x) > 1e-24f && fabsf(rd.y) > 1e-24f && fabsf(rd.z) > 1e-24f;
+}
+
+// Where a ray (ray_by_dist) enters the box (c, h) grown by its margin; `inside`: the origin lies in the grown box.  A box
+// that cannot be judged (non-finite, out of range) is entered at -FLT_MAX, inside.
+__device__ __forceinline__ float cluster_enter(float4 c, float4 h, v3 ro, v3 rd, bool& inside)
+{
+    const float ox = c.x - ro.x, oy = c.y - ro.y, oz = c.z - ro.z;
+    const float fx = fabsf(ox) + h.x, fy = fabsf(oy) + h.y, fz = fabsf(oz) + h.z;
+    const float D2 = fx * fx + fy * fy + fz * fz;
+    inside = true;
+    if (!(D2 >= 1e-12f && D2 <= 1e24f)) return -3.402823466e+38f;
+    const float m = rt_sqrt(D2) * RT_CULL_MARGIN;
+    const float Hx = h.x + m, Hy = h.y + m, Hz = h.z + m;
+    const float ix = rt_rcp(rd.x), iy = rt_rcp(rd.y), iz = rt_rcp(rd.z);
+    const float x0 = (ox - Hx) * ix, x1 = (ox + Hx) * ix;
+    const float y0 = (oy - Hy) * iy, y1 = (oy + Hy) * iy;
+    const float z0 = (oz - Hz) * iz, z1 = (oz + Hz) * iz;
+    inside = fabsf(ox) <= Hx && fabsf(oy) <= Hy && fabsf(oz) <= Hz;
+    return fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+}
+
+__device__ __forceinline__ ClusterRounds cluster_rounds(const SceneLds& sc, v3 ro, v3 rd)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    ClusterRounds cr;
+    cr.enter = -3.402823466e+38f;
+    cr.by_dist = false;
+    if (sc.clusters == nullptr || sc.n_clusters <= 0) { cr.near = 0ull; cr.rest = cluster_mask(sc, ro, rd); return cr; }
+    cr.by_dist = ray_by_dist(rd);
+    bool visit = lane < sc.n_clusters, inside = false;
+    if (visit) {
+        const float4 c = ((const float4*)sc.clusters)[2 * lane], h = ((const float4*)sc.clusters)[2 * lane + 1];
+        visit = cluster_may_hit(c, h, ro, rd);
+        inside = visit;                            // (rays that skip nothing by distance: every round with the first ones)
+        if (visit && cr.by_dist) cr.enter = cluster_enter(c, h, ro, rd, inside);
+    }
+    cr.near = __ballot(visit && inside);
+    cr.rest = __ballot(visit && !inside);
+    return cr;
+}
+
 template <bool HAS_NONSPHERE>
 __device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd, float& best)
 {
@@ -544,20 +608,30 @@ __device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd
     best = 3.402823466e+38f;
     int bi = -1;
     bool nan_seen = false;
-    // the rounds that can hold a hit (all of them without clusters)
-    unsigned long long rounds = cluster_mask(sc, ro, rd);
-    while (rounds != 0ull) {
-        const int j = 64 * __builtin_ctzll(rounds) + lane;
-        rounds &= rounds - 1ull;
-        if (j >= sc.n_hit) continue;
-        float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
-        float t;
-        if (hittable_hit<HAS_NONSPHERE, false>(r0, r1, ro, rd, fa, inv, t)) {
-            nan_seen = nan_seen || (t != t);
-            // slots ascend, scene indices need not: equal distances go to the lower scene index
-            if (!(t >= best) || (sorted && t == best && bi >= 0 && sc.orig[j] < sc.orig[bi])) { best = t; bi = j; }
+    auto scan = [&](unsigned long long rounds) {
+        while (rounds != 0ull) {
+            const int j = 64 * __builtin_ctzll(rounds) + lane;
+            rounds &= rounds - 1ull;
+            if (j >= sc.n_hit) continue;
+            float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
+            float t;
+            if (hittable_hit<HAS_NONSPHERE, false>(r0, r1, ro, rd, fa, inv, t)) {
+                nan_seen = nan_seen || (t != t);
+                // slots ascend, scene indices need not: equal distances go to the lower scene index
+                if (!(t >= best) || (sorted && t == best && bi >= 0 && sc.orig[j] < sc.orig[bi])) { best = t; bi = j; }
+            }
         }
+    };
+    // the rounds that can hold a hit (all of them without clusters): first those around the origin, then what is left of
+    // the others once the best distance so far is known
+    const ClusterRounds cr = cluster_rounds(sc, ro, rd);
+    scan(cr.near);
+    unsigned long long rest = cr.rest;
+    if (rest != 0ull && cr.by_dist && cr.near != 0ull) {
+        const float b = wave_extreme<false>(best);                       // (FLT_MAX: no hit yet, nothing is dropped)
+        rest = __ballot(((rest >> lane) & 1ull) != 0ull && !(cr.enter > fmaxf(b * 1.001f, 0.0f)));
     }
+    scan(rest);
     if (__ballot(nan_seen) != 0ull) return closest_hit_seq<HAS_NONSPHERE>(sc, ro, rd, best);
     // The winner over the lanes: the smallest distance (no-hit lanes carry FLT_MAX, which no hit reaches); two hits at the
     // same distance go to the lower index in the scene.
@@ -587,17 +661,24 @@ __device__ __forceinline__ bool any_hit_coop(const SceneLds& sc, v3 ro, v3 rd, f
     float fa = 4.0f * dot(rd, rd);
     v3 inv = mk(0, 0, 0);
     if (HAS_NONSPHERE) inv = mk(rt_rcp(rd.x), rt_rcp(rd.y), rt_rcp(rd.z));
-    // 64 hittables per round; the first round with an occluder ends the query (any order gives the same boolean)
-    unsigned long long rounds = cluster_mask(sc, ro, rd);
-    while (rounds != 0ull) {
-        const int j = 64 * __builtin_ctzll(rounds) + lane;
-        rounds &= rounds - 1ull;
-        bool o = false;
-        if (j < sc.n_hit) {
-            float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
-            o = occluder_hit<HAS_NONSPHERE, false, LIMITED, false>(r0, r1, ro, rd, fa, inv, limit);
+    // 64 hittables per round; the first round with an occluder ends the query (any order gives the same boolean): the
+    // rounds around the origin first -- what shadows a point is mostly next to it
+    const ClusterRounds cr = cluster_rounds(sc, ro, rd);
+    unsigned long long rest = cr.rest;
+    if (LIMITED && cr.by_dist && limit >= 0.0f)
+        rest = __ballot(((rest >> lane) & 1ull) != 0ull && !(cr.enter > limit * 1.001f));
+    for (int part = 0; part < 2; ++part) {
+        unsigned long long rounds = part == 0 ? cr.near : rest;
+        while (rounds != 0ull) {
+            const int j = 64 * __builtin_ctzll(rounds) + lane;
+            rounds &= rounds - 1ull;
+            bool o = false;
+            if (j < sc.n_hit) {
+                float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
+                o = occluder_hit<HAS_NONSPHERE, false, LIMITED, false>(r0, r1, ro, rd, fa, inv, limit);
+            }
+            if (__ballot(o) != 0ull) return true;
         }
-        if (__ballot(o) != 0ull) return true;
     }
     return false;
 }

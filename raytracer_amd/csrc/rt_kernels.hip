@@ -1716,6 +1716,26 @@ __global__ void debug_cull_kernel(const float* clusters, const unsigned int* slo
     out[i] = cluster_may_hit(cb, ch, ro, rd) ? 1 : 0;
 }
 
+// enter[i] = where ray i enters the grown box of hittable `index`'s cluster as the distance rule of the cooperative
+// scans sees it (rt_device.hpp cluster_rounds); -FLT_MAX where the rule does not apply to the ray or the box
+__global__ void debug_cull_enter_kernel(const float* clusters, const unsigned int* slot_of, int index, const float* rays, int n, float* enter)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(slot_of[index] / 64u);
+    const float4 cb = make_float4(clusters[8 * c + 0], clusters[8 * c + 1], clusters[8 * c + 2], clusters[8 * c + 3]);
+    const float4 ch = make_float4(clusters[8 * c + 4], clusters[8 * c + 5], clusters[8 * c + 6], clusters[8 * c + 7]);
+    v3 ro = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), rd = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    bool inside;
+    enter[i] = ray_by_dist(rd) ? cluster_enter(cb, ch, ro, rd, inside) : -3.402823466e+38f;
+}
+
+hipError_t rt_launch_debug_cull_enter(const float* clusters, const unsigned int* slot_of, int index, const float* rays, int n, float* enter, hipStream_t stream)
+{
+    hipLaunchKernelGGL(debug_cull_enter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, clusters, slot_of, index, rays, n, enter);
+    return hipGetLastError();
+}
+
 hipError_t rt_launch_debug_cull(const float* clusters, const unsigned int* slot_of, int index, const float* rays, int n, unsigned char* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(debug_cull_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, clusters, slot_of, index, rays, n, out);

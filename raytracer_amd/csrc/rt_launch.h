@@ -91,6 +91,7 @@ hipError_t rt_launch_debug_exact_math(unsigned long long* out3, hipStream_t stre
 hipError_t rt_launch_debug_quantise(const float* in, int n, unsigned char* out, hipStream_t stream);
 hipError_t rt_launch_debug_intersect(const float4* hrec, int index, const float* rays, int n, float* out8, hipStream_t stream);
 hipError_t rt_launch_debug_cull(const float* clusters, const unsigned int* slot_of, int index, const float* rays, int n, unsigned char* out, hipStream_t stream);
+hipError_t rt_launch_debug_cull_enter(const float* clusters, const unsigned int* slot_of, int index, const float* rays, int n, float* enter, hipStream_t stream);
 // glow post-process (rt_glow.hip)
 hipError_t rt_launch_glow_downsample(const void* src, int srcW, void* dst, int dW, int dH, hipStream_t stream);
 hipError_t rt_launch_glow_blur(const void* src, void* dst, int w, int h, int size, const float* kernel, hipStream_t stream);

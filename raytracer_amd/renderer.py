@@ -232,6 +232,14 @@ class Renderer:
         self._check(self._lib.rt_debug_cull(self._h, index, rays.ctypes.data, len(rays), out.ctypes.data), "rt_debug_cull")
         return out
 
+    def debug_cull_enter(self, index, rays):
+        """per ray the parameter at which it enters hittable `index`'s cluster box as the distance rule of the large-scene
+        kernels sees it (-FLT_MAX where the rule does not apply)"""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        out = np.zeros(len(rays), dtype=np.float32)
+        self._check(self._lib.rt_debug_cull_enter(self._h, index, rays.ctypes.data, len(rays), out.ctypes.data), "rt_debug_cull_enter")
+        return out
+
 
 def write_ppm(path, rgb):
     """P6 writer with the reference's header (src/main.cpp:423)."""

@@ -194,7 +194,10 @@ def test_cluster_skip_rule_never_skips_a_hit(rt):
     (rt_debug_intersect), for rays aimed to graze: impact parameters within 1e-7 .. 1e-1 of a sphere's radius, lines
     through a cube's corners, edges and faces offset by as little, origins from inside the hittable to 1e6 sizes away
     and behind it, directions with zero components and lengths other than 1, hittables from 1e-3 to 1e4 in size and at
-    large coordinates.  A ray the rule would skip must never hit; and the rule must skip most of the rays that miss."""
+    large coordinates, components of 1e-30 .. 1e-10 (a ray refracted into a glass cube comes out of refract() like that).
+    A ray the rule would skip must never hit; and the rule must skip most of the rays that miss.  The distance rule
+    (rt_debug_cull_enter) likewise: a hit at distance t lies in a box the ray enters no later than max(1.001 t, 0), so a
+    closest-hit query that has a best distance b never drops a cluster holding a hit below b."""
     rs = np.random.RandomState(12345)
     eps = np.array([0.0, 1e-7, 3e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1])
     back = np.array([-3.0, -1.01, -0.5, 0.0, 0.5, 1.01, 2.0, 10.0, 100.0, 1e4, 1e6])
@@ -208,6 +211,9 @@ def test_cluster_skip_rule_never_skips_a_hit(rt):
                 d[k, rs.randint(3)] = 0.0
             elif axis[k] == 2:
                 z = rs.choice(3, 2, replace=False); d[k, z] = 0.0
+            elif axis[k] == 3 and k % 2:                      # ... and of those left, half: one or two tiny components
+                z = rs.choice(3, rs.randint(1, 3), replace=False)
+                d[k, z] = rs.choice([-1.0, 1.0], size=len(z)) * 10.0 ** rs.uniform(-30, -10, size=len(z))
             if not d[k].any():
                 d[k, 0] = 1.0
         d /= np.linalg.norm(d, axis=1, keepdims=True)
@@ -220,7 +226,7 @@ def test_cluster_skip_rule_never_skips_a_hit(rt):
         return u
 
     n = 40000
-    skipped_misses = misses = 0
+    skipped_misses = misses = ruled = 0
     cases = [("sphere", (0.0, 0.0, -5.0), 1.0), ("sphere", (3.0, -2.0, 7.0), 1e-3), ("sphere", (0.0, -1000.0, -4.0), 1000.0),
              ("sphere", (1e5, 2e5, -3e5), 10.0), ("sphere", (0.5, 0.5, 0.5), 1e4),
              ("cube", (-1.0, 0.0, -6.0), (2.0, 1.0, 0.5)), ("cube", (5.0, 5.0, 5.0), (1e-3, 2e-3, 1e-3)),
@@ -256,10 +262,16 @@ def test_cluster_skip_rule_never_skips_a_hit(rt):
         hit = rt.debug_intersect(0, rays)[:, 0] != 0
         may = rt.debug_cull(0, rays) != 0
         assert not (hit & ~may).any(), (kind, a, b, rays[hit & ~may][:3])
+        res = rt.debug_intersect(0, rays)
+        enter = rt.debug_cull_enter(0, rays)
+        late = hit & (enter > np.maximum(np.float32(1.001) * res[:, 1], np.float32(0.0)))
+        assert not late.any(), (kind, a, b, rays[late][:3], res[late][:3, 1], enter[late][:3])
+        ruled += int((hit & (enter > -3e38)).sum())
         misses += int((~hit).sum())
         skipped_misses += int((~hit & ~may).sum())
-    print("skip rule: %d of %d missing rays skipped" % (skipped_misses, misses))
+    print("skip rule: %d of %d missing rays skipped; distance rule checked on %d hits" % (skipped_misses, misses, ruled))
     assert skipped_misses > 0.3 * misses
+    assert ruled > 10000
 
 
 def test_large_scene_more_pixels_than_resident_waves(rt):
