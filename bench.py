@@ -401,13 +401,21 @@ def main():
     for _ in range(args.warmup):
         solo.run(1)
     if in_flight > 1:
-        pipe.run(in_flight)
+        # (untimed) every context several times, then the timed region's own pattern once: the K timed frames take some
+        # 80 ms, and a one-off inside them -- a hardware queue's scratch ring growing at a context's first listed kernel,
+        # clocks still ramping on a fresh box -- showed as 6.1 instead of 3.9 ms per frame in one run of two
+        pipe.run(4 * in_flight)
+        pipe.run(args.steps)
     sync()
     del kernel_ms[:], device_ms[:]
+    import gc
+    gc.collect()
+    gc.disable()                                    # (no collector pause among the host threads of the timed region)
     t0 = time.perf_counter()
     frame = pipe.run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     gather_ms = list(pipe.gather_ms)                 # per frame: this rank's gather + reassembly step
     # untimed: the last frame of the timed region against the CPU oracle (the plain-C port, pinned to the reference by
     # tests/test_oracle_golden.py) on every vstep-th row -- the rows the cpu_baseline leg samples

@@ -438,6 +438,13 @@ __device__ __forceinline__ Hit hit_record(const SceneLds& sc, int idx, v3 ro, v3
 // index; that is what each lane computes over its indices and what the butterfly computes over lanes.  A NaN distance
 // anywhere makes the order of replacements matter (hittablesList.h:25): the wave then repeats the query sequentially.
 #define RT_COOP (-1)
+// (experiments: -DRT_COOP_STATS tallies the cooperative queries; rt_kernels.hip prints the sums after coop_kernel)
+#ifdef RT_COOP_STATS
+__device__ unsigned long long g_coop_stats[12];
+#define RT_CSTAT(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_coop_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define RT_CSTAT(k, v) ((void)0)
+#endif
 
 template <bool HAS_NONSPHERE>
 __device__ __forceinline__ int closest_hit_seq(const SceneLds& sc, v3 ro, v3 rd, float& best);
@@ -625,12 +632,14 @@ __device__ __forceinline__ int closest_hit_coop(const SceneLds& sc, v3 ro, v3 rd
     // the rounds that can hold a hit (all of them without clusters): first those around the origin, then what is left of
     // the others once the best distance so far is known
     const ClusterRounds cr = cluster_rounds(sc, ro, rd);
+    RT_CSTAT(0, 1); RT_CSTAT(1, __popcll(cr.near)); RT_CSTAT(2, __popcll(cr.rest));
     scan(cr.near);
     unsigned long long rest = cr.rest;
     if (rest != 0ull && cr.by_dist && cr.near != 0ull) {
         const float b = wave_extreme<false>(best);                       // (FLT_MAX: no hit yet, nothing is dropped)
         rest = __ballot(((rest >> lane) & 1ull) != 0ull && !(cr.enter > fmaxf(b * 1.001f, 0.0f)));
     }
+    RT_CSTAT(3, __popcll(rest));
     scan(rest);
     if (__ballot(nan_seen) != 0ull) return closest_hit_seq<HAS_NONSPHERE>(sc, ro, rd, best);
     // The winner over the lanes: the smallest distance (no-hit lanes carry FLT_MAX, which no hit reaches); two hits at the
@@ -667,6 +676,7 @@ __device__ __forceinline__ bool any_hit_coop(const SceneLds& sc, v3 ro, v3 rd, f
     unsigned long long rest = cr.rest;
     if (LIMITED && cr.by_dist && limit >= 0.0f)
         rest = __ballot(((rest >> lane) & 1ull) != 0ull && !(cr.enter > limit * 1.001f));
+    RT_CSTAT(4, 1); RT_CSTAT(5, __popcll(cr.near) + __popcll(rest));
     for (int part = 0; part < 2; ++part) {
         unsigned long long rounds = part == 0 ? cr.near : rest;
         while (rounds != 0ull) {
@@ -677,7 +687,8 @@ __device__ __forceinline__ bool any_hit_coop(const SceneLds& sc, v3 ro, v3 rd, f
                 float4 r0 = sc.hrec[2 * j], r1 = sc.hrec[2 * j + 1];
                 o = occluder_hit<HAS_NONSPHERE, false, LIMITED, false>(r0, r1, ro, rd, fa, inv, limit);
             }
-            if (__ballot(o) != 0ull) return true;
+            RT_CSTAT(6, 1);
+            if (__ballot(o) != 0ull) { RT_CSTAT(7, 1); return true; }
         }
     }
     return false;
@@ -842,6 +853,7 @@ __device__ __forceinline__ float light_intensity_coop(const SceneLds& sc, v3 pos
         lx = l.x; ly = l.y; lz = l.z;
     }
     float intensity = 0.085f;
+    RT_CSTAT(8, 1);
     for (int turn = 0; turn < sc.n_lights; ++turn) {
         // the largest term left that could raise the intensity; among equals the first light
         const float best = wave_extreme<true>(my > intensity ? my : -1.0f);

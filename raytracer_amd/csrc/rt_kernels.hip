@@ -145,7 +145,7 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
             float dist;
             int bi;
             const bool listed_query = primary && sc.cl_nprim >= 0;      // a wave's (coop_kernel: a pixel's) candidate lists
-            if (listed_query)                                  bi = closest_hit_ldslist<HAS_NONSPHERE>(sc, sc.cl_prim, sc.cl_nprim, ro, rd, dist);
+            if (listed_query)                                  { RT_CSTAT(9, 1); bi = closest_hit_ldslist<HAS_NONSPHERE>(sc, sc.cl_prim, sc.cl_nprim, ro, rd, dist); }
             else if (!HAS_NONSPHERE && primary && BATCH != RT_COOP) bi = closest_hit_primary<COUNT>(sc, rd, dist, cnt);
             else                                               bi = closest_hit<HAS_NONSPHERE, COUNT, BATCH>(sc, ro, rd, dist, cnt);
             primary = false;
@@ -356,9 +356,9 @@ __device__ __forceinline__ int frame_row(const KernelArgs& a, int r)
     return a.band_rows > 0 ? a.row0 + (r / a.band_rows) * a.band_stride + (r % a.band_rows) : a.row0 + r;
 }
 
-__device__ __forceinline__ PixelId tiled_pixel(const KernelArgs& a)
+__device__ __forceinline__ PixelId tiled_pixel(const KernelArgs& a, int tid = (int)threadIdx.x)
 {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wave = tid >> 6, lane = tid & 63;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     PixelId p;
     p.x = tx * 16 + (wave & 1) * 8 + (lane & 7);
@@ -832,6 +832,7 @@ __global__ __launch_bounds__(BLOCK, (HAS_NONSPHERE || EMISSION) ? 1 : RT_DIRECT_
         dk[k] = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
         fak[k] = 4.0f * dot(dk[k], dk[k]);
     }
+
     v3 acc_color = mk(0, 0, 0), acc_em = mk(0, 0, 0);
     float acc_st = 0.0f;
     // MODE 0: every query over the scene; 1: over the wave's candidate lists; 2: both lists hold at most RT_SMALL_LIST hittables,
@@ -885,10 +886,19 @@ __global__ __launch_bounds__(BLOCK, (HAS_NONSPHERE || EMISSION) ? 1 : RT_DIRECT_
     else if (culled) samples(std::integral_constant<int, 1>());
     else        samples(std::integral_constant<int, 0>());
     const float n = (float)a.samples;
+    // (the pixel's place in the output, worked out again from a thread index the compiler cannot connect with the first
+    // one: kept across the sample loop it cost the sphere-only kernel, at its 80 registers, a 64-bit spill per lane --
+    // 512 B per wave written to scratch and read back, 65 MB of the kernel's 120 MB of HBM writes per 4K frame; four
+    // more registers are still spilled inside the sample loop, which the L2 absorbs: 55 MB written for 24.9 MB of
+    // pixels.  At 5 waves per SIMD nothing spills -- 33 MB -- and a frame takes 4 % longer.)
+    int tid2 = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const PixelId p2 = tiled_pixel(a, tid2);
+    const size_t o2 = (size_t)p2.x + (size_t)p2.r * a.width;
     if (a.rgb)                                                               // main.cpp:318 -> structs.h:12-17
-        store_rgb_quad(a.rgb + o * 3, quantise(acc_color.x / n), quantise(acc_color.y / n), quantise(acc_color.z / n));
+        store_rgb_quad(a.rgb + o2 * 3, quantise(acc_color.x / n), quantise(acc_color.y / n), quantise(acc_color.z / n));
     if (EMISSION && a.emission)                                              // main.cpp:319 -> structs.h:39-43
-        a.emission[o] = make_float4(acc_em.x / n, acc_em.y / n, acc_em.z / n, acc_st / n);
+        a.emission[o2] = make_float4(acc_em.x / n, acc_em.y / n, acc_em.z / n, acc_st / n);
 }
 
 // The listed kernel's waves: candidate lists for the primary segment of every ray, as in the direct kernel (rt_device.hpp
@@ -1593,6 +1603,16 @@ bool rt_launch_coop_fits(int n_hit, int n_lights, int n_mat)
     return coop_lds_bytes(n_hit, n_lights, n_mat) <= 160 * 1024;
 }
 
+#ifdef RT_COOP_STATS
+// (experiments, -DRT_COOP_STATS: the tallies of rt_device.hpp's RT_CSTAT after a frame's coop_kernel)
+__global__ void coop_stats_kernel()
+{
+    printf("[coop stats] closest: %llu queries, rounds near %llu rest %llu (scanned of rest: %llu); any-hit: %llu queries, rounds listed %llu scanned %llu, occluded %llu; light loops: %llu; closest over a pixel's candidate list %llu\n",
+           g_coop_stats[0], g_coop_stats[1], g_coop_stats[2], g_coop_stats[3], g_coop_stats[4], g_coop_stats[5], g_coop_stats[6], g_coop_stats[7], g_coop_stats[8], g_coop_stats[9]);
+    for (int k = 0; k < 12; ++k) g_coop_stats[k] = 0ull;
+}
+#endif
+
 template <class K>
 static hipError_t launch_coop(K k, const KernelArgs& a, int blocks, size_t lds_bytes, hipStream_t stream)
 {
@@ -1614,6 +1634,9 @@ static hipError_t launch_coop(K k, const KernelArgs& a, int blocks, size_t lds_b
     const int resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
     if (blocks > resident) blocks = resident;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(COOP_WAVES * 64), lds_bytes, stream, a);
+#ifdef RT_COOP_STATS
+    hipLaunchKernelGGL(coop_stats_kernel, dim3(1), dim3(1), 0, stream);
+#endif
     return hipGetLastError();
 }
 

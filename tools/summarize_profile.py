@@ -19,7 +19,7 @@ stats = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
 
 # the timed kernels = rt:: kernels launched once per step (the tally build runs once); dominant = largest total time
-timed = [r for r in stats if "rt::" in r["Name"] and int(r["Calls"]) >= 2
+timed = [r for r in stats if ("rt::" in r["Name"] or "rt_relaxed::" in r["Name"]) and int(r["Calls"]) >= 2
          and any(k in r["Name"] for k in ("render_kernel", "direct_kernel", "heavy_kernel", "classify_kernel", "coop_kernel"))]
 # the direct kernel carries ~80 % of a frame's VALU instructions: it leads (large scenes: the cooperative kernel
 # does); then by total time
