@@ -274,7 +274,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--estimate-tally", action="store_true", help="tally every 32nd row and scale instead of the whole frame (large scenes: the exact tally takes most of a minute)")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed frame with the CPU oracle")
-    ap.add_argument("--no-extras", action="store_true", help="skip the legs after the headline: the relaxed-arithmetic variant of the same workload and the glass 1080p frame")
+    ap.add_argument("--no-extras", action="store_true", help="skip the legs after the headline: the relaxed-arithmetic variant of the same workload, the glass 1080p frame and the 2049-hittable 1080p frame")
     ap.add_argument("--flags", type=int, default=0, help="extra rt_params.flags for A/B runs (4 = RT_FLAG_SINGLE_KERNEL, 8 = RT_FLAG_FORCE_SAMPLE_PARALLEL)")
     args = ap.parse_args()
 
@@ -553,6 +553,47 @@ def main():
             r_.upload_scene(scene)
         return leg
 
+    def large_scene_leg(name="many2048_1080p_32spp", frames=3):
+        """BASELINE.json configs[3] (2049 hittables, 8 point lights, 1080p, 32 spp): a driver-timed figure for the large-scene
+        route (direct_kernel<BIG> + coop_kernel).  Its frames fill the GPU by themselves: one at a time, one warm-up frame
+        first.  Exact arithmetic; three rows against the oracle (minutes per row on the CPU beyond that); the ray count is
+        the counting build's on every 32nd row, scaled (the whole frame takes it most of a minute)."""
+        sname, W2, H2, spp2, depth2 = WORKLOADS[name]
+        sc2 = ra.scenes.BUILTIN[sname]()
+        rt_solo.upload_scene(sc2)
+        cam2 = ra.camera35f(sc2, W2, H2)
+        out2 = torch.zeros((H2, W2, 3), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        p2 = rt_solo.params(W2, H2, spp2, depth2, seed)
+        rt_solo.render_rows(cam2, p2, out2)
+        k_ms = []
+        t1 = time.perf_counter()
+        for _ in range(frames):
+            rt_solo.render_rows(cam2, p2, out2)
+            k_ms.append(rt_solo.last_kernel_ms)
+        sec = (time.perf_counter() - t1) / frames
+        step = 32
+        n = H2 // step
+        cnt2 = rt_solo.render_rows(cam2, rt_solo.params(W2, H2, spp2, depth2, seed, row0=0, rows=n, band_rows=1, band_stride=step), out2.clone()[:n], count=True)
+        closest = int(cnt2["closest"] * (H2 / float(n)))
+        leg = {"workload": name, "config": {"scene": sname, "width": W2, "height": H2, "spp": spp2, "max_depth": depth2, "hittables": len(sc2.hittables), "lights": len(sc2.lights)},
+               "ms_per_step": round(sec * 1e3, 3), "value": round(closest / sec / 1e6, 2), "unit": "Mrays/s", "steps": frames, "frames_in_flight": 1,
+               "kernel_ms": round(float(np.mean(k_ms)), 3),
+               "rays": {"closest": closest, "note": "estimate: reference-algorithm queries of every %d-th row, scaled to the frame" % step}}
+        if not args.no_verify:
+            step2 = H2 // 3
+            n2 = (H2 + step2 - 1) // step2
+            w2 = oracle_lib.render_strided(sc2, W2, H2, spp2, depth2, seed, row0=0, rows=n2, row_step=step2, threads=host_threads())[0]
+            bad2 = int((out2[::step2].cpu().numpy() != w2).any(axis=-1).sum())
+            leg["verified"] = {"rows": n2, "row_step": step2, "pixels": int(n2 * W2), "differing_pixels": bad2, "identical": bad2 == 0}
+        pm, pm_path, pm_stale = load_pmc(name)
+        if pm and not pm_stale:
+            pf = pm["per_frame"]
+            leg["roofline"] = {"pmc": pm_path, "valu_issue_frac": round(pf["valu_wave_instructions"] / (leg["kernel_ms"] * 1e-3) / 1e9 / (256 * 4 * 2.4 / 2.0), 4),
+                               "lane_utilisation": round(pf["lane_utilisation"], 4), "traffic": int(pf["hbm_bytes"])}
+        rt_solo.upload_scene(scene)
+        return leg
+
     if rank == 0:
         rays = tot["closest"]                       # primary + secondary closest-hit queries (renderer.h:40)
         sec_per_step = elapsed / args.steps
@@ -619,9 +660,11 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_extras and args.workload == "default4_4k_64spp" and args.flags == 0:
-            progress("extra legs: relaxed arithmetic, glass 1080p")
+            progress("extra legs: relaxed arithmetic, glass 1080p, 2049 hittables 1080p")
             line["relaxed"] = relaxed_leg()
             line["secondary"] = [glass_leg()]
+            progress("glass leg done")
+            line["secondary"].append(large_scene_leg())
         if not args.no_cpu_baseline and world == 1:
             def count_rays(step):
                 n = (H + step - 1) // step
