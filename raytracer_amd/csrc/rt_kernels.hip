@@ -159,11 +159,18 @@ __device__ __forceinline__ PathOut trace_path(const SceneLds& sc, RNG& rng, v3 r
                 Hit h = hit_record<!HAS_NONSPHERE>(sc, bi, ro, rd, dist);
                 v3 offPosition = h.position + h.normal * 0.005f;                 // renderer.h:55
                 if (COUNT) ++cnt.shaded;
-                float intensity = (listed_query && sc.cl_noccl >= 0)
-                    ? light_intensity_ldslist<HAS_NONSPHERE>(sc, sc.cl_occl, sc.cl_noccl, offPosition, h.normal)
-                    : light_intensity<HAS_NONSPHERE, COUNT, PRUNE, BATCH>(sc, offPosition, h.normal, cnt);
                 mat = h.material;
                 const float* m = sc.mats + 10 * mat;
+                // A material whose colour is zero in every channel -- the reference's glass, postgres.h:210 -- shades to
+                // (0 * intensity) * multiplier = 0 whatever the lights say: GetLightIntensity is max(0.085, Lambert terms),
+                // a positive finite number (a NaN term fails `intens > intensity`, lightsList.h:37), and the product keeps
+                // the zero's sign.  Its shadow queries decide nothing and are left out (not by the tallying builds).
+                const bool black = PRUNE && !COUNT && m[0] == 0.0f && m[1] == 0.0f && m[2] == 0.0f;
+                float intensity = 0.085f;
+                if (!black)
+                    intensity = (listed_query && sc.cl_noccl >= 0)
+                        ? light_intensity_ldslist<HAS_NONSPHERE>(sc, sc.cl_occl, sc.cl_noccl, offPosition, h.normal)
+                        : light_intensity<HAS_NONSPHERE, COUNT, PRUNE, BATCH>(sc, offPosition, h.normal, cnt);
                 color = (mk(m[0], m[1], m[2]) * intensity) * mult;               // renderer.h:64
                 if (EMISSION) { emission = mk(m[6], m[7], m[8]); strength = m[9]; }
                 if (depth <= maxTotalDepth) {                                    // renderer.h:68

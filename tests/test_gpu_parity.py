@@ -395,6 +395,55 @@ def test_executed_tally_prunes_only_shadow_queries(rt):
     assert ref["shadow"] == ref["shaded"] * len(sc.lights)
 
 
+def test_black_materials_shade_without_their_shadow_queries(rt):
+    """A material whose colour is zero in every channel shades to (0 * intensity) * multiplier whatever the lights say, so
+    the production kernels leave its shadow queries out (trace_path).  Same bytes and bits as the reference's, which asks
+    them: black mirrors (rough and perfect), black glass, a black reflect-and-refract material, channels of -0.0 (the
+    product keeps the zero's sign), a colour of 1e-30 as the control that must NOT take the shortcut; point lights and a
+    directional one; seen directly, in mirrors and through glass; small scene (listed kernels) and large (cooperative).
+    The tallying builds still ask and count every query the reference asks."""
+    for big in (False, True):
+        sc = scenes.Scene(name="black_big" if big else "black")
+        scenes._default_materials(sc)                                      # 3 = the reference's glass: colour (0, 0, 0)
+        bm = sc.material((0.0, 0.0, 0.0), 0.2, 0.8, 0.0)                   # black rough mirror
+        bp = sc.material((-0.0, 0.0, -0.0), 0.0, 0.9, 0.0)                 # perfect mirror, negative zeros
+        bx = sc.material((0.0, -0.0, 0.0), 0.05, 0.5, 1.5, (0.2, 0.9, 0.1), 2.0)    # reflects and refracts, glows
+        nb = sc.material((1e-30, 0.0, 0.0), 0.1, 0.7, 0.0)                 # not black
+        sc.sphere((0.0, -1000.0, -4.0), 1000.0, 0)
+        sc.sphere((0.0, 1.0, -4.0), 1.0, bm)
+        sc.sphere((-2.5, 1.0, -3.0), 1.0, bp)
+        sc.sphere((2.5, 1.0, -3.0), 1.0, bx)
+        sc.sphere((-1.2, 0.6, -1.0), 0.6, 3)
+        sc.cube((1.0, 0.0, -1.5), (0.8, 0.8, 0.8), 3)
+        sc.sphere((4.5, 1.2, -6.0), 1.2, nb)
+        sc.cube((-4.5, 0.0, -7.0), (1.5, 2.0, 1.5), bm)
+        sc.dirlight((-0.25, -0.75, 0.45))
+        sc.pointlight((2.0, 6.0, 1.0))
+        sc.pointlight((-5.0, 3.0, -2.0))
+        if big:
+            rs = np.random.RandomState(11)
+            for k in range(280):
+                x, z, r = rs.uniform(-30, 30), rs.uniform(-60, -10), rs.uniform(0.2, 0.6)
+                m = (0, 1, 2, 3, bm, bp, bx, nb)[k % 8]
+                if k % 3 == 2:
+                    sc.cube((x, 0.0, z), (r, r, r), m)
+                else:
+                    sc.sphere((x, r, z), r, m)
+        W, H, samples, depth, seed = (160, 90, 2, 8, 3) if big else (200, 120, 6, 12, 3)
+        want_rgb, want_em, want_cnt = oracle_lib.render(sc, W, H, samples, depth, seed, threads=8)
+        rt.upload_scene(sc)
+        rgb, em, _ = rt.render(W, H, samples, depth, seed, emission=True)
+        assert np.array_equal(rgb, want_rgb), sc.name
+        assert np.array_equal(em.view(np.uint32), want_em.view(np.uint32)), sc.name
+        cam = ra.camera35f(sc, W, H)
+        p = rt.params(W, H, samples, depth, seed)
+        a = np.zeros((H, W, 3), np.uint8)
+        ref = rt.render_rows(cam, p, a, count=True)
+        assert np.array_equal(a, want_rgb)
+        for k in ("closest", "shadow", "tests", "rand_draws"):
+            assert ref[k] == want_cnt[k], (sc.name, k)
+
+
 def test_kernel_pair_equals_single_general_kernel(rt):
     """Default path = classify + direct kernel + listed general kernel; RT_FLAG_SINGLE_KERNEL = the general kernel over
     every pixel.  Same bytes; checked against the oracle on a band."""
