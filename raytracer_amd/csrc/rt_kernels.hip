@@ -55,11 +55,12 @@ constexpr int BLOCK = 256;
 #ifndef RT_LISTED_LISTS
 #define RT_LISTED_LISTS 1
 #endif
-// coop_kernel: the path state in scalar registers (rt_device.hpp uni()).  Off: measured on C4
-// it takes the register spills from 43 to 16 and the kernel's HBM traffic from 194 to 94 GB per frame, at 3 % more
-// instructions and 846 instead of 833 ms -- the spills are not what the frame waits for.
+// coop_kernel: the path state in scalar registers (rt_device.hpp uni()): the kernel's 64 lanes hold one pixel's path, and
+// telling the compiler so takes the register spills at 80 VGPRs from 45 to 19 and the kernel's HBM traffic on C4 from
+// 215 to 96 GB per frame, for 1.4 % more instructions and the same time (547 against 551 ms; round 2 measured it 1.5 %
+// slower and left it off -- the spills were not, and are not, what the frame waits for, but they were most of its traffic).
 #ifndef RT_COOP_UNIFORM
-#define RT_COOP_UNIFORM 0
+#define RT_COOP_UNIFORM 1
 #endif
 // how many of the first four samples must have drawn the same count for a pixel to be handed over (measured: with 3
 // or 2, C5 gets slower -- 186 / 210 instead of 175 ms -- and nothing gets faster)
