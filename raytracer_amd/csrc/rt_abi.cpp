@@ -41,6 +41,13 @@
 #ifndef RT_HEAVY_MIN_WORK_SEQ
 #define RT_HEAVY_MIN_WORK_SEQ RT_HEAVY_MIN_WORK
 #endif
+// frames in flight: the listed kernel runs with a wave per workgroup (LaunchTraits::wave_groups) when the context's last
+// frame of this scene kept it busy for at least this long -- then the frames' listed waves are what the SIMDs' slots
+// are short of (glass 1080p: 160 - 360 ms per launch, 27.5 -> 22.3 ms per frame), while short listed kernels (the 4K
+// frame: 5 ms) lose by it (3.79 -> 3.85 ms).  The environment variable of this name overrides it (0: always).
+#ifndef RT_WAVE_GROUPS_MS
+#define RT_WAVE_GROUPS_MS 20.0
+#endif
 struct rt_ctx {
     int device = -1;
     hipStream_t stream = nullptr;      // everything but the listed general kernel
@@ -52,6 +59,9 @@ struct rt_ctx {
     hipEvent_t ev_wait = nullptr;           // wait_stream()
     unsigned long long* h_back = nullptr;   // 8 pinned words: a frame's read-backs (a copy to pageable memory waits inside hipMemcpyAsync, polling)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, ev_list = nullptr, ev_gen = nullptr;
+    hipEvent_t ev_l0 = nullptr, ev_l1 = nullptr;   // around the listed kernel of a frame in flight
+    bool listed_timed = false;                     // ev_l0 / ev_l1 were recorded by the last frame
+    float listed_ms = 0.0f;                        // what they measured last (0: nothing yet for this scene)
     float last_ms = 0.0f, last_total_ms = 0.0f, last_gather_ms = 0.0f;
     hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;   // rt_gather_rows: around the RCCL group and the reassembly
     int last_hip = 0;
@@ -301,6 +311,8 @@ int rt_create(rt_ctx** out, int device_ordinal)
     if (e == hipSuccess) e = hipEventCreate(&ctx->evm);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_list, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gen, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_l0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_l1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_g0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_g1);
@@ -340,6 +352,8 @@ void rt_destroy(rt_ctx* ctx)
     if (ctx->evm) (void)hipEventDestroy(ctx->evm);
     if (ctx->ev_list) (void)hipEventDestroy(ctx->ev_list);
     if (ctx->ev_gen) (void)hipEventDestroy(ctx->ev_gen);
+    if (ctx->ev_l0) (void)hipEventDestroy(ctx->ev_l0);
+    if (ctx->ev_l1) (void)hipEventDestroy(ctx->ev_l1);
     if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
     if (ctx->ev_g0) (void)hipEventDestroy(ctx->ev_g0);
     if (ctx->ev_g1) (void)hipEventDestroy(ctx->ev_g1);
@@ -556,6 +570,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_soa* s)
         ctx->scene_bytes = bytes;
     }
     ctx->has_scene = false;
+    ctx->listed_timed = false; ctx->listed_ms = 0.0f;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scene, img.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->d_hrec = (const float4*)ctx->d_scene;
@@ -689,6 +704,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
     t.count = count;
     t.listed = false;
     t.rng_scratch = false;
+    t.wave_groups = false;
     t.prune = (p->flags & RT_FLAG_COUNT_LIKE_REFERENCE) == 0;
     // frames on the bounce stack <= reflection parents (max_depth) + refraction parents (66)
     t.deep = refraction_chain_bound() + p->max_depth > RT_STACK_SHALLOW || p->max_depth > RT_PEND_SHALLOW - 1;
@@ -744,6 +760,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                 // them (4K / 64 spp: 5.83 -> 5.73 ms) and what a sequence of frames wants (6 in flight: 4K frame 5.59 ->
                 // 5.39 ms, glass 1080p 65 -> 51 ms per frame; measured A/B on one box).
                 const double direct_work = (double)(npix - n_listed) * (double)p->samples;
+                bool no_handover = false;                  // the listed kernel keeps every pixel: no heavy / resume launch
                 tg.rng_scratch = (p->flags & RT_FLAG_SEQUENCE) != 0 || direct_work >= RT_DIRECT_BOUND_WORK;
                 // Long pixels leave the listed kernel after their first sample and are finished one wave per pixel,
                 // one lane per sample, by the heavy kernel behind it (DESIGN.md "sample-parallel pixels").
@@ -781,6 +798,15 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     double min_work = ((p->flags & RT_FLAG_SEQUENCE) && seq_min_work >= 1.0 ? seq_min_work : (double)RT_HEAVY_MIN_WORK)
                                       / (per_bounce > 1.0 ? per_bounce : 1.0);
                     g2.heavy_min_work = force ? 0u : (unsigned int)(min_work < 1.0 ? 1.0 : min_work > 4.0e9 ? 4.0e9 : min_work);
+                    // With frames in flight the hand-over pays where the frame's direct kernel keeps the GPU busy long
+                    // enough: its rounds trace some samples twice, which is free beside a long direct kernel and shortens
+                    // the frame's tail, and costs throughput where other frames' kernels would have used the slots
+                    // (measured by share of the 4K frame and on the glass frame).  Below the bar that
+                    // rng_scratch uses for "bound by its direct kernel" nothing is handed over (and nothing launched for it).
+                    if ((p->flags & RT_FLAG_SEQUENCE) && direct_work < RT_DIRECT_BOUND_WORK && !force && !getenv("RT_HEAVY_MIN_WORK_SEQ")) {
+                        g2.heavy_min_work = 0xFFFFFFFFu;
+                        no_handover = true;
+                    }
                 }
                 // Frames in flight (RT_FLAG_SEQUENCE): the listed kernels go onto the context's one stream (the direct
                 // kernel onto one of the device's shared streams, below; behind the listed kernels on this stream when
@@ -832,8 +858,20 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     // one launch owns the whole list (one dispatch less per frame; the split below buys latency for a
                     // frame on its own)
                     g2.listed_mode = RT_MODE_ALL;
+                    // (the last frame of this context has been waited for: its events are complete)
+                    static const double wave_groups_ms = getenv("RT_WAVE_GROUPS_MS") ? atof(getenv("RT_WAVE_GROUPS_MS")) : RT_WAVE_GROUPS_MS;
+                    if (ctx->listed_timed) {
+                        float ms = 0.0f;
+                        if (hipEventElapsedTime(&ms, ctx->ev_l0, ctx->ev_l1) == hipSuccess) ctx->listed_ms = ms;
+                        else (void)hipGetLastError();
+                        ctx->listed_timed = false;
+                    }
+                    tg.wave_groups = wave_groups_ms <= 0.0 || (double)ctx->listed_ms >= wave_groups_ms;
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_l0, s2));
                     HIP_TRY(ctx, rt_launch_render(g2, tg, s2));
-                    HIP_TRY(ctx, rt_launch_heavy(g2, tg, s2));
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_l1, s2));
+                    ctx->listed_timed = true;
+                    if (!no_handover) HIP_TRY(ctx, rt_launch_heavy(g2, tg, s2));
                 } else if (g2.heavy_cap > 0) {
                     // the steady long pixels: first samples, hand-over, heavy kernel, resume kernel ...
                     g2.listed_mode = RT_MODE_STEADY;

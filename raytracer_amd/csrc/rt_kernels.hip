@@ -51,6 +51,10 @@ constexpr int BLOCK = 256;
 #ifndef RT_LISTED_WAVES
 #define RT_LISTED_WAVES 4
 #endif
+// the listed render_kernel of a sequence's long frames (LaunchTraits::wave_groups): threads per workgroup
+#ifndef RT_LISTED_SEQ_BLOCK
+#define RT_LISTED_SEQ_BLOCK 64
+#endif
 // the listed render_kernel's per-wave candidate lists for the primary segment (listed_wave_lists)
 #ifndef RT_LISTED_LISTS
 #define RT_LISTED_LISTS 1
@@ -376,9 +380,10 @@ __device__ __forceinline__ PixelId tiled_pixel(const KernelArgs& a, int tid = (i
     return p;
 }
 
+template <int WG = BLOCK>
 __device__ __forceinline__ PixelId listed_pixel(const KernelArgs& a)
 {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const int i = blockIdx.x * WG + threadIdx.x;
     PixelId p;
     p.active = (unsigned int)i < (unsigned int)a.list_count;
     const unsigned int o = p.active ? a.list[i] : 0u;
@@ -918,7 +923,7 @@ __global__ __launch_bounds__(BLOCK, (HAS_NONSPHERE || EMISSION) ? 1 : RT_DIRECT_
 // hittables (larger ones: no lists, every query over the scene).
 constexpr int LISTED_LIST = 32;
 
-template <bool HAS_NONSPHERE>
+template <bool HAS_NONSPHERE, int STRIDE = BLOCK>
 __device__ __forceinline__ void listed_wave_lists(const KernelArgs& a, SceneLds& sc, const float* dirs, bool mine,
                                                   unsigned short* lp, unsigned short* lo)
 {
@@ -930,7 +935,7 @@ __device__ __forceinline__ void listed_wave_lists(const KernelArgs& a, SceneLds&
         bool any = false;
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
-            const v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+            const v3 rd = mk(dirs[(3 * k + 0) * STRIDE], dirs[(3 * k + 1) * STRIDE], dirs[(3 * k + 2) * STRIDE]);
             const float fa = 4.0f * dot(rd, rd);
             v3 inv = mk(0, 0, 0);
             if (HAS_NONSPHERE) inv = mk(rt_rcp(rd.x), rt_rcp(rd.y), rt_rcp(rd.z));
@@ -943,7 +948,7 @@ __device__ __forceinline__ void listed_wave_lists(const KernelArgs& a, SceneLds&
     unsigned int listed = 0u;                                  // hittables on the occluder list, one bit each
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
-        const v3 rd = mk(dirs[(3 * k + 0) * BLOCK], dirs[(3 * k + 1) * BLOCK], dirs[(3 * k + 2) * BLOCK]);
+        const v3 rd = mk(dirs[(3 * k + 0) * STRIDE], dirs[(3 * k + 1) * STRIDE], dirs[(3 * k + 2) * STRIDE]);
         float dist;
         const int bi = closest_hit_ldslist<HAS_NONSPHERE>(sc, lp, nprim, origin, rd, dist);
         const bool hit = mine && bi >= 0;
@@ -974,33 +979,69 @@ __device__ __forceinline__ void listed_wave_lists(const KernelArgs& a, SceneLds&
 // render_kernel: the general per-pixel driver.  LISTED: over the pixel list built by classify / scatter, at raised
 // wave priority (these are the long pixels; the direct kernel's waves fill in around them).  Otherwise over 16x16
 // tiles of every pixel (tallying builds).
-template <bool LISTED, bool LDS_RNG, bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND>
-__global__ __launch_bounds__(BLOCK, LISTED ? RT_LISTED_WAVES : RT_MIN_WAVES) void render_kernel(KernelArgs a)
+#if defined(RT_WAVE_TIMES) && !defined(RT_RELAXED_TU)
+// (experiments, -DRT_WAVE_TIMES: every wave of the listed kernel leaves when it started (100 MHz clock), how long it ran,
+// HW_ID and XCC_ID | workgroup << 4; tools/wave_times.py reads them back and draws the occupancy of frames in flight)
+#define RT_WAVE_TIMES_CAP (1 << 20)
+__device__ uint4 g_wave_times[RT_WAVE_TIMES_CAP];
+__device__ unsigned int g_wave_times_n;
+extern "C" __attribute__((visibility("default"))) int rt_debug_wave_times(void* out, int cap)
+{
+    unsigned int n = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wave_times_n), 4) != hipSuccess) return -1;
+    if (n > RT_WAVE_TIMES_CAP) n = RT_WAVE_TIMES_CAP;
+    if ((int)n > cap) n = (unsigned int)cap;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), (size_t)n * 16) != hipSuccess) return -1;
+    const unsigned int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_times_n), &zero, 4) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif
+
+// WG: threads of a workgroup.  BLOCK, or RT_LISTED_SEQ_BLOCK for the listed kernel of frames in flight whose listed waves
+// live long (rt_abi.cpp): the kernel holds 4 waves per SIMD (100 - 117 registers), a workgroup holds its slots until its
+// last wave has finished, and with a wave per workgroup every finished wave's slot goes to the next frame's waves
+// (glass 1080p, 16 frames in flight: 2.5 of the 4 slots hold a live wave with 256 threads; 27.5 -> 22.3 ms per frame).
+// Short listed kernels keep BLOCK: the dispatcher packs single waves onto SIMDs that hold listed waves already, and a
+// listed wave in company is slower.
+template <bool LISTED, bool LDS_RNG, bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, int WG = BLOCK>
+__global__ __launch_bounds__(WG, LISTED ? RT_LISTED_WAVES : RT_MIN_WAVES) void render_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
+#if defined(RT_WAVE_TIMES) && !defined(RT_RELAXED_TU)
+    const unsigned long long wt0 = wall_clock64();
+#endif
     SceneLds sc;
     float* lds_free;
     stage_scene(a, lds, sc, lds_free);
     if (LISTED) __builtin_amdgcn_s_setprio(3);
 
-    const PixelId p = LISTED ? listed_pixel(a) : tiled_pixel(a);
+    const PixelId p = LISTED ? listed_pixel<WG>(a) : tiled_pixel(a);
     Counters cnt = { 0, 0, 0, 0, 0 };
     // the listed kernel has few, long waves: it trades LDS and registers for shorter dependent chains
     constexpr int BATCH = LISTED ? RT_LISTED_BATCH : 1;
-    unsigned int* rng_lds = (unsigned int*)(lds_free + 12 * BLOCK) + threadIdx.x;
+    unsigned int* rng_lds = (unsigned int*)(lds_free + 12 * WG) + threadIdx.x;
     bool dirs_ready = false;
 #if RT_LISTED_LISTS
     if (LISTED && !COUNT && PRUNE && sc.n_hit <= LISTED_LIST) {
         // (the lists sit behind the per-thread words: 2 x LISTED_LIST entries per wave; rt_launch_lds_bytes has the room)
-        unsigned short* lp = (unsigned short*)(lds_free + 12 * BLOCK + (LDS_RNG ? 32 * BLOCK : 0)) + (threadIdx.x >> 6) * (2 * LISTED_LIST);
-        primary_directions(a, lds_free + threadIdx.x, p.x, p.y);
+        unsigned short* lp = (unsigned short*)(lds_free + 12 * WG + (LDS_RNG ? 32 * WG : 0)) + (threadIdx.x >> 6) * (2 * LISTED_LIST);
+        primary_directions<WG>(a, lds_free + threadIdx.x, p.x, p.y);
         dirs_ready = true;
-        listed_wave_lists<HAS_NONSPHERE>(a, sc, lds_free + threadIdx.x, p.active, lp, lp + LISTED_LIST);
+        listed_wave_lists<HAS_NONSPHERE, WG>(a, sc, lds_free + threadIdx.x, p.active, lp, lp + LISTED_LIST);
     }
 #endif
     if (p.active)
-        render_pixel<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, LDS_RNG, BATCH, LISTED>(a, sc, lds_free + threadIdx.x, rng_lds, p.x, p.y, p.r, cnt, true, dirs_ready);
+        render_pixel<EMISSION, MIXED, HAS_NONSPHERE, COUNT, PRUNE, MAXSP, MAXPEND, LDS_RNG, BATCH, LISTED, WG>(a, sc, lds_free + threadIdx.x, rng_lds, p.x, p.y, p.r, cnt, true, dirs_ready);
     if (COUNT && p.active) flush_counters(a, cnt);
+#if defined(RT_WAVE_TIMES) && !defined(RT_RELAXED_TU)
+    if (LISTED && (threadIdx.x & 63) == 0) {
+        const unsigned int i = atomicAdd(&g_wave_times_n, 1u);
+        if (i < RT_WAVE_TIMES_CAP)
+            g_wave_times[i] = make_uint4((unsigned int)wt0, (unsigned int)(wall_clock64() - wt0), __builtin_amdgcn_s_getreg(63492),
+                                         (__builtin_amdgcn_s_getreg(63508) & 0xFu) | (blockIdx.x << 4));
+    }
+#endif
 }
 
 // heavy_kernel: one wave per handed-over pixel, one lane per sample (DESIGN.md "sample-parallel pixels").  A pixel's
@@ -1475,14 +1516,14 @@ using namespace RT_NS;
 #endif
 
 template <class K>
-static hipError_t launch_with_lds(K k, const KernelArgs& a, int blocks, size_t lds_bytes, hipStream_t stream)
+static hipError_t launch_with_lds(K k, const KernelArgs& a, int blocks, size_t lds_bytes, hipStream_t stream, int threads = BLOCK)
 {
     if (blocks <= 0) return hipSuccess;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
@@ -1521,27 +1562,34 @@ static size_t listed_lds_bytes(int n_hit, int n_lights, int n_mat)
     return rt_launch_lds_bytes(n_hit, n_lights, n_mat) + (size_t)32 * BLOCK * 4;
 }
 
-template <bool LISTED, bool LDS_RNG, bool EMISSION, bool MIXED, bool HAS_NONSPHERE>
+template <bool LISTED, bool LDS_RNG, bool EMISSION, bool MIXED, bool HAS_NONSPHERE, int WG = BLOCK>
 static hipError_t launch_general(const KernelArgs& a, bool deep, int blocks, size_t lds, hipStream_t s)
 {
-    if (deep) return launch_with_lds(render_kernel<LISTED, LDS_RNG, EMISSION, MIXED, HAS_NONSPHERE, false, true, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, s);
-    return launch_with_lds(render_kernel<LISTED, LDS_RNG, EMISSION, MIXED, HAS_NONSPHERE, false, true, RT_STACK_SHALLOW, RT_PEND_SHALLOW>, a, blocks, lds, s);
+    if (deep) return launch_with_lds(render_kernel<LISTED, LDS_RNG, EMISSION, MIXED, HAS_NONSPHERE, false, true, RT_STACK_DEEP, RT_PEND_DEEP, WG>, a, blocks, lds, s, WG);
+    return launch_with_lds(render_kernel<LISTED, LDS_RNG, EMISSION, MIXED, HAS_NONSPHERE, false, true, RT_STACK_SHALLOW, RT_PEND_SHALLOW, WG>, a, blocks, lds, s, WG);
 }
 
 // The general per-pixel kernel: over the pixel list (a.list / a.list_count) when t.listed, else over all tiles.
 hipError_t rt_launch_render(const KernelArgs& a, const LaunchTraits& t, hipStream_t stream)
 {
-    const int blocks = t.listed ? (a.list_count + BLOCK - 1) / BLOCK : a.tiles_x * a.tiles_y;
+    int blocks = t.listed ? (a.list_count + BLOCK - 1) / BLOCK : a.tiles_x * a.tiles_y;
     size_t lds = rt_launch_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
     // large scenes leave no room for the generators next to the staged records: they stay in scratch then
     const bool lds_rng = t.listed && RT_LISTED_LDS_RNG && listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat) <= 160 * 1024 && !t.rng_scratch;
     if (lds_rng) lds = listed_lds_bytes(a.n_hit, a.n_lights, a.n_mat);
+    // a wave per workgroup (render_kernel's WG; the per-thread words shrink with the workgroup)
+    const bool wave_groups = t.listed && !lds_rng && t.wave_groups;
+    if (wave_groups) {
+        blocks = (a.list_count + RT_LISTED_SEQ_BLOCK - 1) / RT_LISTED_SEQ_BLOCK;
+        lds -= (size_t)12 * (BLOCK - RT_LISTED_SEQ_BLOCK) * 4;
+    }
     // the tally builds are the most general ones: emission, mixed, all primitive types, deep stack
     if (t.count && !t.prune) return launch_with_lds(render_kernel<false, false, true, true, true, true, false, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream);
     if (t.count)             return launch_with_lds(render_kernel<false, false, true, true, true, true, true, RT_STACK_DEEP, RT_PEND_DEEP>, a, blocks, lds, stream);
 #define RT_DISPATCH(E, M, N) if (t.emission == E && t.mixed == M && t.nonsphere == N) \
         return !t.listed ? launch_general<false, false, E, M, N>(a, t.deep, blocks, lds, stream) \
              : lds_rng   ? launch_general<true, true, E, M, N>(a, t.deep, blocks, lds, stream)   \
+             : wave_groups ? launch_general<true, false, E, M, N, RT_LISTED_SEQ_BLOCK>(a, t.deep, blocks, lds, stream) \
                          : launch_general<true, false, E, M, N>(a, t.deep, blocks, lds, stream);
     RT_ALL_VARIANTS(RT_DISPATCH)
 #undef RT_DISPATCH

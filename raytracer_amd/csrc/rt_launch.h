@@ -70,6 +70,7 @@ struct LaunchTraits {
     bool listed;     // render_kernel over KernelArgs::list instead of over all tiles
     bool prune;      // with count: tally the production kernel's pruned shadow queries instead of the reference's
     bool rng_scratch;// listed render_kernel: keep the generators in scratch although LDS has room (rt_abi.cpp says when)
+    bool wave_groups;// listed render_kernel with its generators in scratch: one wave per workgroup (rt_abi.cpp says when)
 };
 
 size_t rt_launch_lds_bytes(int n_hit, int n_lights, int n_mat);

@@ -14,7 +14,9 @@ next frame although the consumer, who takes frames in order, has not come to its
 Frames are independent (each pixel of each frame re-seeds from (x, y, seed_base)), so the bytes of every frame are
 those of an unpipelined render.
 """
+import os
 import threading
+import time
 
 import torch
 
@@ -48,6 +50,7 @@ class FramePipeline:
         # per frame of the last run(): time of the gather + reassembly step -- device time from HIP events when it went
         # through rt_gather_rows, wall time of the torch.distributed gather + rt_deinterleave_bands otherwise
         self.gather_ms = []
+        self.pace_ms = float(os.environ.get("RT_PACE_MS", "0")) or None
 
     def _buffers(self):
         """rank 0's gather and frame buffers, allocated once (no allocation inside the frame loop)"""
@@ -77,6 +80,7 @@ class FramePipeline:
         stop = threading.Event()
         take = threading.Lock()
         next_frame = [0]
+        last_start = [0.0]
 
         def producer(worker):
             # frames are taken in order; frame k lives in block k % B, which is free once frame k - B was consumed
@@ -91,6 +95,12 @@ class FramePipeline:
                     free[slot].acquire()
                     if stop.is_set():
                         return
+                    if self.pace_ms:
+                        with take:
+                            t = max(time.perf_counter(), last_start[0] + self.pace_ms * 1e-3)
+                            last_start[0] = t
+                        while time.perf_counter() < t:
+                            time.sleep(max(0.0, min(t - time.perf_counter(), 0.0005)))
                     self.render(worker, self.blocks[slot], first_frame + k)
                     ready[slot].release()
             except BaseException as e:          # handed to the consumer, which raises it
@@ -103,7 +113,6 @@ class FramePipeline:
         for t in threads:
             t.start()
         last = None
-        import time
         self.gather_ms = []
         try:
             for k in range(n_frames):
