@@ -51,9 +51,15 @@ constexpr int BLOCK = 256;
 #ifndef RT_LISTED_WAVES
 #define RT_LISTED_WAVES 4
 #endif
-// the listed render_kernel of a sequence's long frames (LaunchTraits::wave_groups): threads per workgroup
+// the listed render_kernel of a sequence's long frames (LaunchTraits::wave_groups): threads per workgroup, and the waves
+// per SIMD its registers must leave room for (5: 96 registers and 7 - 51 of them spilled, where 4 leaves 100 - 117 and
+// spills nothing -- the frames this variant is for are short of slots: glass 1080p in flight 23.4 -> 22.3 ms per frame;
+// 6 is slower again)
 #ifndef RT_LISTED_SEQ_BLOCK
 #define RT_LISTED_SEQ_BLOCK 64
+#endif
+#ifndef RT_LISTED_SEQ_WAVES
+#define RT_LISTED_SEQ_WAVES 5
 #endif
 // the listed render_kernel's per-wave candidate lists for the primary segment (listed_wave_lists)
 #ifndef RT_LISTED_LISTS
@@ -1005,7 +1011,7 @@ extern "C" __attribute__((visibility("default"))) int rt_debug_wave_times(void* 
 // Short listed kernels keep BLOCK: the dispatcher packs single waves onto SIMDs that hold listed waves already, and a
 // listed wave in company is slower.
 template <bool LISTED, bool LDS_RNG, bool EMISSION, bool MIXED, bool HAS_NONSPHERE, bool COUNT, bool PRUNE, int MAXSP, int MAXPEND, int WG = BLOCK>
-__global__ __launch_bounds__(WG, LISTED ? RT_LISTED_WAVES : RT_MIN_WAVES) void render_kernel(KernelArgs a)
+__global__ __launch_bounds__(WG, LISTED ? (WG == BLOCK ? RT_LISTED_WAVES : RT_LISTED_SEQ_WAVES) : RT_MIN_WAVES) void render_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
 #if defined(RT_WAVE_TIMES) && !defined(RT_RELAXED_TU)
