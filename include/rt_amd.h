@@ -121,6 +121,11 @@ typedef struct {
                                            Bounce pixels and every other flag keep the exact arithmetic.  Ignored by the
                                            tallying builds and RT_FLAG_SINGLE_KERNEL (they run the exact general kernel)  */
 
+#define RT_FLAG_FORCE_WAVE_GROUPS     256 /* test hook, with RT_FLAG_SEQUENCE: the listed kernel runs with one wave per
+                                           workgroup whatever the context measured on its last frame (DESIGN.md section 9,
+                                           "what frames in flight wait for"; without the hook a context chooses that
+                                           launch shape for frames whose listed kernel took 20 ms or more).  Same bytes  */
+
 /* Query tallies with the reference's meaning: primary = W*rows*samples*4; closest = TraceRay closest-hit queries
  * (src/renderer.h:40); shadow = hasIntersect / point-light occlusion queries (directionalLight.h:13); tests =
  * primitive intersect() calls; rand_draws = RANDOM_UNIT calls; shaded = closest-hit queries that hit (one

@@ -17,6 +17,7 @@ RT_FLAG_SINGLE_KERNEL = 4
 RT_FLAG_FORCE_SAMPLE_PARALLEL = 8
 RT_FLAG_SEQUENCE = 16
 RT_FLAG_RELAXED = 128
+RT_FLAG_FORCE_WAVE_GROUPS = 256
 RT_COMM_ID_BYTES = 128
 RT_ERR_RCCL = -9
 

@@ -37,7 +37,8 @@
 #endif
 // the same bar under RT_FLAG_SEQUENCE; the environment variable of this name overrides it. Measured (DESIGN.md section 5,
 // 3c): 200000 makes glass 1080p 8 % faster with 16 frames in flight and the last frames of a short 4K sequence slower
-// (they run alone, where the hand-over is what shortens them), so it stays equal to RT_HEAVY_MIN_WORK.
+// (they run alone, where the hand-over is what shortens them), so it stays equal to RT_HEAVY_MIN_WORK.  Round 3: under
+// RT_FLAG_SEQUENCE only frames bound by their direct kernel hand pixels over at all (render_rows_impl, no_handover).
 #ifndef RT_HEAVY_MIN_WORK_SEQ
 #define RT_HEAVY_MIN_WORK_SEQ RT_HEAVY_MIN_WORK
 #endif
@@ -866,7 +867,7 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                         else (void)hipGetLastError();
                         ctx->listed_timed = false;
                     }
-                    tg.wave_groups = wave_groups_ms <= 0.0 || (double)ctx->listed_ms >= wave_groups_ms;
+                    tg.wave_groups = (p->flags & RT_FLAG_FORCE_WAVE_GROUPS) != 0 || wave_groups_ms <= 0.0 || (double)ctx->listed_ms >= wave_groups_ms;
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_l0, s2));
                     HIP_TRY(ctx, rt_launch_render(g2, tg, s2));
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_l1, s2));

@@ -87,7 +87,9 @@ while time.time() < t_end:
     rows = int(rs.randint(1, H - row0 + 1))
     flags = int(rs.choice([0, 0, 0, _abi.RT_FLAG_SINGLE_KERNEL, _abi.RT_FLAG_FORCE_SAMPLE_PARALLEL]))
     if rs.randint(3) == 0:
-        flags |= _abi.RT_FLAG_SEQUENCE          # the route of frames in flight (one listed launch, serial pixels sorted by cost)
+        flags |= _abi.RT_FLAG_SEQUENCE          # the route of frames in flight (one listed launch, hand-over only in frames bound by their direct kernel)
+        if rs.randint(2) == 0:
+            flags |= _abi.RT_FLAG_FORCE_WAVE_GROUPS     # ... with the listed kernel one wave per workgroup
     want, want_em, _ = oracle_lib.render(sc, W, H, samples, depth, seed, row0=row0, rows=rows, threads=15)
     rt.upload_scene(sc)
     cam = ra.camera35f(sc, W, H)

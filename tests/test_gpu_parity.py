@@ -587,6 +587,38 @@ def test_sequence_hint_gives_the_same_bytes(rt, name, W, H, samples, depth):
         assert np.array_equal(rgb, out[0][0]) and np.array_equal(em.view(np.uint32), out[0][1].view(np.uint32))
 
 
+@pytest.mark.parametrize("name,W,H,samples,depth", [("default4", 333, 77, 8, 10), ("glass_mirror", 200, 120, 16, 12), ("cube", 96, 64, 3, 5),
+                                                  ("plane", 130, 50, 5, 6), ("default4", 64, 64, 64, 3)])
+def test_wave_per_workgroup_listed_kernel_gives_the_same_bytes(rt, name, W, H, samples, depth):
+    """Frames in flight whose listed kernel is long launch it with one wave per workgroup (render_kernel<..., WG = 64>:
+    a context chooses that from what its last frame measured; RT_FLAG_FORCE_WAVE_GROUPS is the test hook).  A launch
+    shape, not arithmetic: the bytes, the emission bits and -- on the frame the oracle renders here -- the reference's
+    pixels are the same, with and without an emission buffer, and the frames after it on the same context as well
+    (the context's own choice, whatever it measured)."""
+    from raytracer_amd import _abi
+    sc = scenes.BUILTIN[name]()
+    rt.upload_scene(sc)
+    cam = ra.camera35f(sc, W, H)
+    ref = np.zeros((H, W, 3), np.uint8); ref_em = np.zeros((H, W, 4), np.float32)
+    rt.render_rows(cam, rt.params(W, H, samples, depth, 23), ref, ref_em)
+    if name == "cube":
+        want = oracle_lib.render(sc, W, H, samples, depth, 23)[0]
+        assert np.array_equal(ref, want)
+    forced = _abi.RT_FLAG_SEQUENCE | _abi.RT_FLAG_FORCE_WAVE_GROUPS
+    for flags in (forced, forced, _abi.RT_FLAG_SEQUENCE):
+        rgb = np.zeros((H, W, 3), np.uint8); em = np.zeros((H, W, 4), np.float32)
+        rt.render_rows(cam, rt.params(W, H, samples, depth, 23, flags=flags), rgb, em)
+        assert np.array_equal(rgb, ref) and np.array_equal(em.view(np.uint32), ref_em.view(np.uint32))
+        rgb2 = np.zeros((H, W, 3), np.uint8)
+        rt.render_rows(cam, rt.params(W, H, samples, depth, 23, flags=flags), rgb2)
+        assert np.array_equal(rgb2, ref)
+    # together with the sample-parallel hook (that kernel then hands pixels over), and outside a sequence (ignored)
+    for flags in (forced | _abi.RT_FLAG_FORCE_SAMPLE_PARALLEL, _abi.RT_FLAG_FORCE_WAVE_GROUPS):
+        rgb = np.zeros((H, W, 3), np.uint8)
+        rt.render_rows(cam, rt.params(W, H, samples, depth, 23, flags=flags), rgb)
+        assert np.array_equal(rgb, ref)
+
+
 def test_frames_in_flight_equal_frames_one_at_a_time(rt):
     """raytracer_amd/pipeline.py: several contexts rendering different frames at once on one GPU, from host threads,
     produce the bytes of the same frames rendered alone (glass: listed, sample-parallel and resume kernels overlap
