@@ -832,8 +832,22 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     if (n_listed < npix) { HIP_TRY(ctx, launch_direct(a, t, ctx->stream)); direct_done = true; }
                     HIP_TRY(ctx, rt_launch_coop(g2, tg, s2));
                 } else if (sequence) {
+                    // a long listed kernel (this context's last frame of the scene says): one wave per workgroup
+                    // (the last frame of this context has been waited for: its events are complete)
+                    static const double wave_groups_ms = getenv("RT_WAVE_GROUPS_MS") ? atof(getenv("RT_WAVE_GROUPS_MS")) : RT_WAVE_GROUPS_MS;
+                    if (ctx->listed_timed) {
+                        float ms = 0.0f;
+                        if (hipEventElapsedTime(&ms, ctx->ev_l0, ctx->ev_l1) == hipSuccess) ctx->listed_ms = ms;
+                        else (void)hipGetLastError();
+                        ctx->listed_timed = false;
+                    }
+                    tg.wave_groups = (p->flags & RT_FLAG_FORCE_WAVE_GROUPS) != 0 || wave_groups_ms <= 0.0 || (double)ctx->listed_ms >= wave_groups_ms;
+                    // ... and such a frame's direct kernel stays on the context's own stream, behind the listed kernel (a
+                    // few ms on top of hundreds): sixteen contexts' streams and the shared ones are more streams than
+                    // hardware queues, and a direct kernel that shares a queue with another frame's listed kernel waits
+                    // for all of it (glass 1080p, 16 in flight: 22.4-22.8 -> 21.3-21.8 ms per frame)
                     static const int shared_n = std::min(RT_SEQ_DIRECT_MAX, getenv("RT_SEQ_DIRECT_STREAMS") ? atoi(getenv("RT_SEQ_DIRECT_STREAMS")) : RT_SEQ_DIRECT_STREAMS);
-                    if (shared_n > 0 && s2 == ctx->stream && !no_alloc && ctx->counted && n_listed < npix) {
+                    if (shared_n > 0 && s2 == ctx->stream && !no_alloc && ctx->counted && n_listed < npix && !tg.wave_groups) {
                         // this frame's direct kernel: onto the next shared stream, behind the classification (ev_list);
                         // the context's stream waits for it at the end of the frame (ev_gen).  One lock around the
                         // three calls, so that no other context's kernel gets between this kernel and its event.
@@ -859,15 +873,6 @@ static int render_rows_impl(rt_ctx* ctx, const rt_camera35f* cam, const rt_param
                     // one launch owns the whole list (one dispatch less per frame; the split below buys latency for a
                     // frame on its own)
                     g2.listed_mode = RT_MODE_ALL;
-                    // (the last frame of this context has been waited for: its events are complete)
-                    static const double wave_groups_ms = getenv("RT_WAVE_GROUPS_MS") ? atof(getenv("RT_WAVE_GROUPS_MS")) : RT_WAVE_GROUPS_MS;
-                    if (ctx->listed_timed) {
-                        float ms = 0.0f;
-                        if (hipEventElapsedTime(&ms, ctx->ev_l0, ctx->ev_l1) == hipSuccess) ctx->listed_ms = ms;
-                        else (void)hipGetLastError();
-                        ctx->listed_timed = false;
-                    }
-                    tg.wave_groups = (p->flags & RT_FLAG_FORCE_WAVE_GROUPS) != 0 || wave_groups_ms <= 0.0 || (double)ctx->listed_ms >= wave_groups_ms;
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_l0, s2));
                     HIP_TRY(ctx, rt_launch_render(g2, tg, s2));
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_l1, s2));
