@@ -40,9 +40,17 @@ constexpr int BLOCK = 256;
 #endif
 // waves per SIMD the sphere-only direct kernel's register allocation must leave room for (80 VGPRs at 6; left alone it
 // takes 85 and runs at 4.7 instead of 5.4 resident waves per SIMD; the variants with planes / cubes or an emission
-// buffer want 100 - 160 and are left alone)
+// buffer: below)
 #ifndef RT_DIRECT_WAVES
 #define RT_DIRECT_WAVES 6
+#endif
+// ... and the variants with planes / cubes or an emission buffer: 96 registers at 5 (left alone: 100 - 157; 4 - 83 of
+// them spilled then).  Not for the kernel's own speed (a frame alone takes the same time) but for frames in flight whose
+// listed waves live long: a SIMD that holds five of those (96 registers each) has room for a direct wave of this size as
+// soon as one of them ends, and the direct kernels of glass 1080p no longer wait ~ 85 ms each for room (22.7 -> 20.3 -
+// 21.3 ms per frame with 16 in flight; 4, 6 or 8 waves: 21.8 / 20.9 - 22.2 / 20.6 - 20.9)
+#ifndef RT_DIRECT_NS_WAVES
+#define RT_DIRECT_NS_WAVES 5
 #endif
 // scenes with at least this many hittables: direct_kernel<.., BIG>
 #ifndef RT_DIRECT_BIG
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(const unsigned short* __
 // candidate lists are built from the clusters some ray of the wave may hit (rt_device.hpp cluster_mask) instead of from
 // the whole scene.
 template <bool EMISSION, bool HAS_NONSPHERE, bool CULL = (RT_DIRECT_CULL != 0), bool BIG = false>
-__global__ __launch_bounds__(BLOCK, (HAS_NONSPHERE || EMISSION) ? 1 : RT_DIRECT_WAVES) void direct_kernel(KernelArgs a)
+__global__ __launch_bounds__(BLOCK, (HAS_NONSPHERE || EMISSION) ? RT_DIRECT_NS_WAVES : RT_DIRECT_WAVES) void direct_kernel(KernelArgs a)
 {
     extern __shared__ float4 lds[];
     SceneLds sc;
